@@ -1,0 +1,169 @@
+/*
+ * vgan_hip.h -- C ABI of libvgan_hip.so: the MI355X (gfx950) kernels behind the V-GAN training
+ * hot path (reference: jcribeiro98/V-GAN, src/vgan.py:597-621 and src/models/ *.py).
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; each entry point below replaces
+ * the ATen op sequence of one reference module call, cited as file:line of the reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 (unless typed otherwise), row-major, with an
+ *     explicit leading dimension (elements);  the caller owns and allocates every buffer,
+ *     including workspaces;  the library keeps no state between calls (the frozen RBF bandwidth
+ *     lives in a caller-owned device scalar);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never synchronises
+ *     the host, never allocates, and is therefore HIP-graph capturable;
+ *   - return value: 0 = VGAN_OK, otherwise an error code; vgan_last_error() gives the text.
+ */
+#ifndef VGAN_HIP_H
+#define VGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGAN_OK 0
+#define VGAN_ERR_ARG 1  /* bad shape / null pointer / unsupported configuration */
+#define VGAN_ERR_HIP 2  /* a HIP runtime call or launch failed */
+
+#define VGAN_ABI_VERSION 1
+
+typedef void* vgan_stream_t; /* hipStream_t */
+
+int vgan_abi_version(void);
+const char* vgan_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generator_big / Encoder / Decoder Linear layers  (src/models/Generator.py:61-66,
+ * src/models/Detector.py:8-13,24-29: nn.Linear == addmm; autograd: two mm per layer)
+ *   W is PyTorch layout [out, in].
+ * ------------------------------------------------------------------------------------------- */
+/* y[n,out] = x[n,in] . W^T + b            (b may be NULL) */
+int vgan_linear_forward(const float* x, int ldx, const float* W, int ldw, const float* b,
+                        float* y, int ldy, int n, int in, int out, vgan_stream_t stream);
+/* dx[n,in] = dy[n,out] . W */
+int vgan_linear_backward_input(const float* dy, int lddy, const float* W, int ldw,
+                               float* dx, int lddx, int n, int in, int out, vgan_stream_t stream);
+/* dW[out,in] = dy^T . x ;  db[out] = column sums of dy   (db may be NULL) */
+int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx,
+                                float* dW, int lddw, float* db, int n, int in, int out,
+                                vgan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * upper_softmax + projection  (src/models/Generator.py:18-22, src/vgan.py:616 `U * batch`)
+ *   logits [n,d] -> S = softmax rows, U = (S < 1/d ? S : 1), and the two halves of the stacked
+ *   MMD operand Z = [X_batch ; U * X_batch]:  Zx[i] = X_batch[i], Zy[i] = U[i] * X_batch[i]
+ *   (row stride ldz; columns d..ldz-1 are not written: pre-zero them to pad the feature dimension)
+ *   with squared row norms sqx[n], sqy[n].  S, U are dense [n,d].  Zx/sqx may be NULL.
+ *   The shuffled-batch gather of the DataLoader (src/vgan.py:578-584, :599) is fused in:
+ *   X_batch row i = data[ rows[(t % row_batches) * row_stride + row_offset + i] ], where `rows` is a
+ *   whole epoch's table of shuffled indices and t = *row_cursor is the device-side step counter
+ *   (row_cursor == NULL: t = 0;  rows == NULL: X_batch row i = data[row_offset + i]).  U may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int vgan_mask_project_forward(const float* logits, int ldl, const float* data, int ldd,
+                              const int32_t* rows, const uint64_t* row_cursor, int row_batches,
+                              int row_stride, int row_offset, float* S, float* U, float* Zx, float* Zy,
+                              int ldz, float* sqx, float* sqy, int n, int d, vgan_stream_t stream);
+/* out[i, :d] = data[rows[i], :d], sq[i] = |out[i]|^2 (sq may be NULL): batch rows a rank needs as
+ * Gram columns but holds no mask for (data-parallel runs keep the data set replicated). */
+int vgan_gather_rows(const float* data, int ldd, const int32_t* rows, const uint64_t* row_cursor,
+                     int row_batches, int row_stride, int row_offset, float* out, int ldo,
+                     float* sq, int n, int d, vgan_stream_t stream);
+/* dlogits = softmax-Jacobian( [S < 1/d] * (gU + penalty_grad) ), the autograd of Generator.py:19-21.
+ * colkey (may be NULL): packed column arg-max keys from vgan_colmax; row r of column j gets
+ * -pen_weight/d added when it holds column j's maximum (topk(U,1,0), Mmd_loss_constrained.py:50). */
+int vgan_mask_backward(const float* gU, int ldg, const float* S, int lds, const uint64_t* colkey,
+                       float pen_weight, int row_offset, float* dlogits, int ldo, int n, int d,
+                       vgan_stream_t stream);
+/* colkey[j] = max over rows of pack(U[i,j], row_offset + i)  (value in the high 32 bits, ~row in
+ * the low 32 bits; lowest row wins ties).  from_softmax != 0: the input is S and U is derived from
+ * it; otherwise the input is U itself (must be > 0).  part: workspace [chunks*d] u64 with
+ * chunks = vgan_colmax_chunks(n). */
+int vgan_colmax_chunks(int n);
+int vgan_colmax(const float* S, int lds, int from_softmax, int row_offset, uint64_t* part,
+                uint64_t* colkey, int n, int d, vgan_stream_t stream);
+/* dense U from S (for callers that need the mask tensor itself) */
+int vgan_mask_from_softmax(const float* S, int lds, float* U, int ldu, int n, int d, vgan_stream_t stream);
+/* plain row softmax -> upper_softmax for a dense generator output (no projection) */
+int vgan_upper_softmax_forward(const float* logits, int ldl, float* S, float* U, int n, int d,
+                               vgan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RBF + MMDLossConstrained  (src/models/Mmd_loss_constrained.py:16-26, 42-50)
+ *
+ * The 2n x 2n kernel matrix is never materialised.  The Gram tiles g = Z_I . Z_J^T run on the
+ * fp32 MFMA; the epilogue forms L = |z_i|^2 + |z_j|^2 - 2g (clamped at 0), t = exp(-L/(4 bw)) and
+ * the five-bandwidth sum K = t + t^2 + t^4 + t^8 + t^16, accumulates the block sums, and writes
+ *     Wg[i - wrow0, j] = sgn(i,j) * (2/n^2) * dK/dL        (sgn = +1 same half, -1 across halves)
+ * for the rows whose gradient is needed, so that  dZ_i = 2 (rowsum(Wg_i) z_i - (Wg . Z)_i).
+ *
+ * Work is described by a tile table (host-built by vgan_mmd_build_tiles, uploaded by the caller):
+ * each entry is 8 int32 {r0, c0, rlim, clim, flags, 0,0,0}.
+ * ------------------------------------------------------------------------------------------- */
+#define VGAN_TILE 64           /* Gram tile edge */
+#define VGAN_TILE_INTS 8
+#define VGAN_TF_SLOT_MASK 3    /* 0 = XX, 1 = XY, 2 = YY  block sum the tile contributes to */
+#define VGAN_TF_TWICE 4        /* off-diagonal tile of a symmetric block: counted twice */
+#define VGAN_TF_STORE 8        /* write Wg tile */
+#define VGAN_TF_MIRROR 16      /* also write the transposed tile (symmetric block) */
+#define VGAN_TF_NEG 32         /* sgn = -1 (rows and columns in different halves) */
+
+/* grad_mode: 0 = no gradient (sums only), 1 = gradient for the Y rows only (Wg is [n, 2n],
+ * wrow0 = n), 2 = gradient for all rows (Wg is [2n, 2n], wrow0 = 0).
+ * Row-sharded data parallel: rank `rank` of `world` owns rows [rank*n/world, (rank+1)*n/world)
+ * of each half; its table covers exactly the pairs (own row, any column), without symmetry.
+ * Returns the number of tiles (or -1 if cap is too small); out may be NULL to query the count. */
+int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int32_t* out, int cap);
+
+/* partial[tiles*4] (float): per tile {sum K, sum L, 0, 0}.  calibrate != 0: only sum L is
+ * produced (first-call bandwidth, Mmd_loss_constrained.py:16-20) and bw/Wg are not touched. */
+int vgan_mmd_gram(const float* Z, int ldz, const float* sq, int n, int p, const float* bw,
+                  const int32_t* tiles, int ntiles, int calibrate,
+                  float* Wg, int ldw, int wrow0, float* partial, vgan_stream_t stream);
+/* stats[4] (double): {Sxx, Sxy, Syy, sumL} += reduction of partial[] by tile slot (deterministic).
+ * zero_first != 0 clears stats before accumulating. */
+int vgan_mmd_reduce(const float* partial, const int32_t* tiles, int ntiles, double* stats,
+                    int zero_first, vgan_stream_t stream);
+/* bw[0] = stats[3] / (N^2 - N), N = 2n   (Mmd_loss_constrained.py:18-19) */
+int vgan_mmd_set_bandwidth(const double* stats, int n, float* bw, vgan_stream_t stream);
+/* loss[0] = (Sxx - 2 Sxy + Syy)/n^2 + weight * mean_j(1 - colmax_j)   (Mmd_loss_constrained.py:47-50)
+ * colkey may be NULL (weight term skipped).  loss_accum (may be NULL) += loss * accum_scale;
+ * step_counter (may be NULL) += 1  (device-side step index for the Philox noise stream). */
+int vgan_mmd_loss(const double* stats, const uint64_t* colkey, int n, int d, float weight,
+                  float* loss, float* loss_accum, float accum_scale, uint64_t* step_counter,
+                  vgan_stream_t stream);
+/* dZ[i - wrow0, :] = 2 (rowsum(Wg_i) z_i - Wg_i . Z) for the nr rows starting at wrow0;
+ * if mul != NULL the result is multiplied elementwise by mul[i - wrow0, :] (the `U * batch`
+ * product rule: gU = dY * X).  Z is [ncols, p], Wg is [nr, ncols]. */
+int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr,
+                      int ncols, int p, const float* mul, int ldmul, float* out, int ldo,
+                      vgan_stream_t stream);
+/* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
+int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch.optim.Adadelta over one flat parameter buffer  (src/vgan.py:567-568, :619)
+ *   g += wd*p; v = rho v + (1-rho) g^2; delta = sqrt(a+eps)/sqrt(v+eps) g; a = rho a + (1-rho) delta^2;
+ *   p -= lr*delta.   grad_scale multiplies g first (1 for plain training).
+ * ------------------------------------------------------------------------------------------- */
+int vgan_adadelta_step(float* p, const float* g, float* sq_avg, float* acc_delta, int64_t count,
+                       float lr, float rho, float eps, float weight_decay, float grad_scale,
+                       vgan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Noise feed  (src/vgan.py:610 `noise_tensor.normal_()`): standard normals from a counter-based
+ * Philox4x32-10 stream + Box-Muller, keyed by (seed, *step_counter); replay-safe under HIP graphs.
+ * ------------------------------------------------------------------------------------------- */
+int vgan_noise_normal(float* z, int64_t count, uint64_t seed, const uint64_t* step_counter,
+                      uint64_t stream_id, vgan_stream_t stream);
+
+/* sum of squared differences: out[0] (+)= scale * sum((a-b)^2)  -- `__distance(x,y,'L2')`,
+ * src/vgan.py:58-59, and its gradient  ga (+)= gscale*(a-b), gb (+)= -gscale*(a-b). */
+int vgan_mse(const float* a, int lda, const float* b, int ldb, int n, int d, float scale,
+             float* out, int accumulate, vgan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGAN_HIP_H */

@@ -1,0 +1,119 @@
+// nn.Linear forward/backward on the fp32 MFMA (Generator_big / Encoder / Decoder layers).
+// Reference ops replaced: src/models/Generator.py:61-66, src/models/Detector.py:8-13,24-29
+// (F.linear == addmm forward; autograd's two mm per layer backward).
+#include "gemm_core.hpp"
+
+namespace vgan {
+
+constexpr int LBM = 64, LBN = 64, LBK = 16;
+
+// y = x . W^T + b           A = x (KC), B = W (KC)
+template <int VEC>
+__global__ __launch_bounds__(kBlock, 2) void linear_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                              int ldw, const float* __restrict__ b, float* __restrict__ y,
+                                                              int ldy, int n, int in, int out) {
+    using G = GemmTile<LBM, LBN, LBK, KC, KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    f32x16 acc[G::WM][G::WN];
+    zero_acc(acc);
+    G::template run<false>(x, ldx, W, ldw, m0, n0, n, out, in, lds, nullptr, acc);
+    const int col = n0 + G::sub_col(0);
+    const float bias = (b != nullptr && col < out) ? b[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + G::sub_row(0, r);
+        if (row < n && col < out) y[(long)row * ldy + col] = acc[0][0][r] + bias;
+    }
+}
+
+// dx = dy . W               A = dy (KC, K = out), B(j=in, k=out) = W[k*ldw + j] (MC)
+template <int VEC>
+__global__ __launch_bounds__(kBlock, 2) void linear_bwd_input_kernel(const float* __restrict__ dy, int lddy,
+                                                                    const float* __restrict__ W, int ldw, float* __restrict__ dx,
+                                                                    int lddx, int n, int in, int out) {
+    using G = GemmTile<LBM, LBN, LBK, KC, MC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    f32x16 acc[G::WM][G::WN];
+    zero_acc(acc);
+    G::template run<false>(dy, lddy, W, ldw, m0, n0, n, in, out, lds, nullptr, acc);
+    const int col = n0 + G::sub_col(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + G::sub_row(0, r);
+        if (row < n && col < in) dx[(long)row * lddx + col] = acc[0][0][r];
+    }
+}
+
+// dW = dy^T . x ; db = colsum(dy)    A(i=out, k=row) = dy[k*lddy + i] (MC), B(j=in, k=row) = x[k*ldx + j] (MC)
+template <int VEC>
+__global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_kernel(const float* __restrict__ dy, int lddy,
+                                                                     const float* __restrict__ x, int ldx, float* __restrict__ dW,
+                                                                     int lddw, float* __restrict__ db, int n, int in, int out) {
+    using G = GemmTile<LBM, LBN, LBK, MC, MC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    __shared__ float side[LBM];
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    f32x16 acc[G::WM][G::WN];
+    zero_acc(acc);
+    const bool do_bias = (db != nullptr) && (blockIdx.x == 0);
+    if (do_bias)
+        G::template run<true>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc);
+    else
+        G::template run<false>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc);
+    const int col = n0 + G::sub_col(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + G::sub_row(0, r);
+        if (row < out && col < in) dW[(long)row * lddw + col] = acc[0][0][r];
+    }
+    if (do_bias && threadIdx.x < LBM && m0 + threadIdx.x < out) db[m0 + threadIdx.x] = side[threadIdx.x];
+}
+
+static inline dim3 grid_for(int rows, int cols) { return dim3((cols + LBN - 1) / LBN, (rows + LBM - 1) / LBM, 1); }
+
+}  // namespace vgan
+
+using namespace vgan;
+
+extern "C" int vgan_linear_forward(const float* x, int ldx, const float* W, int ldw, const float* b, float* y, int ldy, int n,
+                                   int in, int out, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(x && W && y && n > 0 && in > 0 && out > 0 && ldx >= in && ldw >= in && ldy >= out);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (in % 4 == 0) && (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(x) && aligned16(W);
+    if (vec)
+        hipLaunchKernelGGL(linear_fwd_kernel<4>, grid_for(n, out), dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out);
+    else
+        hipLaunchKernelGGL(linear_fwd_kernel<1>, grid_for(n, out), dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_linear_backward_input(const float* dy, int lddy, const float* W, int ldw, float* dx, int lddx, int n, int in,
+                                          int out, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(dy && W && dx && n > 0 && in > 0 && out > 0 && lddy >= out && ldw >= in && lddx >= in);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldw % 4 == 0) && aligned16(dy) && aligned16(W);
+    if (vec)
+        hipLaunchKernelGGL(linear_bwd_input_kernel<4>, grid_for(n, in), dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
+    else
+        hipLaunchKernelGGL(linear_bwd_input_kernel<1>, grid_for(n, in), dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, float* db,
+                                           int n, int in, int out, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(dy && x && dW && n > 0 && in > 0 && out > 0 && lddy >= out && ldx >= in && lddw >= in);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldx % 4 == 0) && aligned16(dy) && aligned16(x);
+    if (vec)
+        hipLaunchKernelGGL(linear_bwd_params_kernel<4>, grid_for(out, in), dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in,
+                           out);
+    else
+        hipLaunchKernelGGL(linear_bwd_params_kernel<1>, grid_for(out, in), dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in,
+                           out);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}

@@ -1,0 +1,342 @@
+// RBF + MMDLossConstrained on gfx950 without ever materialising the 2n x 2n kernel matrix.
+// Reference ops replaced: src/models/Mmd_loss_constrained.py:16-26 (cdist**2, bandwidth, 5x exp, sum)
+// and :42-50 (vstack, block means, penalty), plus their autograd (EuclideanDistBackward, exp, mean).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gemm_core.hpp"
+
+namespace vgan {
+
+struct TileDesc {
+    int r0, c0, rlim, clim, flags, pad0, pad1, pad2;
+};
+static_assert(sizeof(TileDesc) == VGAN_TILE_INTS * 4, "tile descriptor layout");
+
+constexpr int GT = VGAN_TILE;  // 64 x 64 Gram tile: one 32x32 MFMA sub-tile per wave
+constexpr int GBK = 16;
+
+// ---- Gram tile + fused kernel epilogue ----------------------------------------------------
+// CALIB: only sum of L (first-call bandwidth).  Otherwise: sum of K = t + t^2 + t^4 + t^8 + t^16 with
+// t = exp(-L / (4 bw)), i.e. sum_k exp(-L / (bw m_k)), m = {4, 2, 1, .5, .25}, and (optionally) the
+// gradient weights Wg = sgn * (2/n^2) * dK/dL with dK/dL = -(1/bw) (t/4 + t^2/2 + t^4 + 2 t^8 + 4 t^16).
+template <int VEC, bool CALIB>
+__global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ sq,
+                                                            int n, int p, const float* __restrict__ bw_ptr,
+                                                            const TileDesc* __restrict__ tiles, float* __restrict__ Wg, int ldw,
+                                                            int wrow0, float* __restrict__ partial) {
+    using G = GemmTile<GT, GT, GBK, KC, KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    __shared__ float red[8];
+    const TileDesc td = tiles[blockIdx.x];
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    G::template run<false>(Z, ldz, Z, ldz, td.r0, td.c0, td.rlim, td.clim, p, lds, nullptr, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = td.c0 + G::sub_col(0);
+    const bool jok = j < td.clim;
+    const float sj = jok ? sq[j] : 0.f;
+    float ksum = 0.f, lsum = 0.f;
+
+    float c2 = 0.f, wscale = 0.f;
+    if constexpr (!CALIB) {
+        const float bw = bw_ptr[0];
+        c2 = -1.4426950408889634f / (4.f * bw);  // exp(-L/(4bw)) = exp2(L * c2)
+        const float sgn = (td.flags & VGAN_TF_NEG) ? -1.f : 1.f;
+        wscale = -sgn * 2.f / ((float)n * (float)n * bw);
+    }
+    const bool store = (!CALIB) && (td.flags & VGAN_TF_STORE) && Wg != nullptr;
+    const bool mirror = store && (td.flags & VGAN_TF_MIRROR);
+    float wv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = td.r0 + G::sub_row(0, r);
+        const bool ok = jok && (i < td.rlim);
+        const float si = (i < td.rlim) ? sq[i] : 0.f;
+        const float L = fmaxf(si + sj - 2.f * acc[0][0][r], 0.f);
+        if constexpr (CALIB) {
+            lsum += ok ? L : 0.f;
+        } else {
+            const float t = __builtin_amdgcn_exp2f(L * c2);  // v_exp_f32
+            const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+            const float K = ((t + t2) + (t4 + t8)) + t16;
+            ksum += ok ? K : 0.f;
+            const float w = wscale * (((0.25f * t + 0.5f * t2) + (t4 + 2.f * t8)) + 4.f * t16);
+            wv[r] = w;
+            if (store && ok) Wg[(long)(i - wrow0) * ldw + j] = w;
+        }
+    }
+    if constexpr (!CALIB) {
+        if (mirror && jok) {  // Wg[j - wrow0, i] = w: rows (r&3) are 4 consecutive i -> one 16-byte store when aligned
+            const int ibase = td.r0 + (wave >> 1) * (GT / 2) + 4 * (lane >> 5);
+            float* dst = Wg + (long)(j - wrow0) * ldw;
+            const bool v4 = ((ldw & 3) == 0) && ((td.r0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i0 = ibase + 8 * q;
+                if (v4 && i0 + 3 < td.rlim) {
+                    *reinterpret_cast<float4*>(dst + i0) = make_float4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (i0 + e < td.rlim) dst[i0 + e] = wv[4 * q + e];
+                }
+            }
+        }
+    }
+    ksum = wave_sum(ksum);
+    lsum = wave_sum(lsum);
+    if (lane == 0) {
+        red[wave] = ksum;
+        red[4 + wave] = lsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 o;
+        o.x = (red[0] + red[1]) + (red[2] + red[3]);
+        o.y = (red[4] + red[5]) + (red[6] + red[7]);
+        o.z = 0.f;
+        o.w = 0.f;
+        reinterpret_cast<float4*>(partial)[blockIdx.x] = o;
+    }
+}
+
+// ---- deterministic reduction of the per-tile partials into the four block statistics ------
+__global__ void mmd_reduce_kernel(const float* __restrict__ partial, const TileDesc* __restrict__ tiles, int ntiles,
+                                  double* __restrict__ stats, int zero_first) {
+    __shared__ double red[4][4];
+    double s[4] = {0, 0, 0, 0};
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        const int fl = tiles[t].flags;
+        const double w = (fl & VGAN_TF_TWICE) ? 2.0 : 1.0;
+        const float4 pv = reinterpret_cast<const float4*>(partial)[t];
+        s[fl & VGAN_TF_SLOT_MASK] += w * (double)pv.x;
+        // sum of L over the FULL Z x Z matrix: the XY block is computed once but occurs twice (XY and YX)
+        s[3] += (((fl & VGAN_TF_SLOT_MASK) == 1) ? 2.0 : w) * (double)pv.y;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s[q] = wave_sum(s[q]);
+        if (lane == 0) red[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        double v = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+        stats[q] = zero_first ? v : stats[q] + v;
+    }
+}
+
+__global__ void mmd_set_bandwidth_kernel(const double* __restrict__ stats, int n, float* __restrict__ bw) {
+    const double N = 2.0 * n;
+    bw[0] = (float)(stats[3] / (N * N - N));
+}
+
+__global__ void mmd_loss_kernel(const double* __restrict__ stats, const unsigned long long* __restrict__ colkey, int n, int d,
+                                float weight, float* __restrict__ loss, float* __restrict__ loss_accum, float accum_scale,
+                                unsigned long long* __restrict__ step_counter) {
+    __shared__ double red[4];
+    double pen = 0.0;
+    if (colkey != nullptr)
+        for (int j = threadIdx.x; j < d; j += blockDim.x) pen += 1.0 - (double)colkey_value(colkey[j]);
+    pen = wave_sum(pen);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pen = (red[0] + red[1]) + (red[2] + red[3]);
+        const double nn = (double)n * (double)n;
+        const double v = (stats[0] - 2.0 * stats[1] + stats[2]) / nn + (colkey ? (double)weight * pen / (double)d : 0.0);
+        loss[0] = (float)v;
+        if (loss_accum) loss_accum[0] += (float)(v * (double)accum_scale);
+        if (step_counter) step_counter[0] += 1ull;
+    }
+}
+
+// ---- backward: dZ_i = 2 (rowsum(Wg_i) z_i - (Wg . Z)_i), optionally times mul ---------------
+// A = Wg [nr, ncols] (KC), B(j = feature, k = Z row) = Z[k*ldz + j] (MC).
+template <int VEC>
+__global__ __launch_bounds__(kBlock, 2) void mmd_backward_kernel(const float* __restrict__ Wg, int ldw, const float* __restrict__ Z,
+                                                                int ldz, int wrow0, int nr, int ncols, int p,
+                                                                const float* __restrict__ mul, int ldmul, float* __restrict__ out,
+                                                                int ldo) {
+    using G = GemmTile<GT, GT, GBK, KC, MC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    __shared__ float rs[GT];
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    G::template run<true>(Wg, ldw, Z, ldz, m0, n0, nr, p, ncols, lds, rs, acc);
+    const int col = n0 + G::sub_col(0);
+    if (col >= p) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lrow = G::sub_row(0, r);
+        const int row = m0 + lrow;
+        if (row < nr) {
+            float v = 2.f * (rs[lrow] * Z[(long)(wrow0 + row) * ldz + col] - acc[0][0][r]);
+            if (mul != nullptr) v *= mul[(long)row * ldmul + col];
+            out[(long)row * ldo + col] = v;
+        }
+    }
+}
+
+__global__ void row_sqnorm_kernel(const float* __restrict__ Z, int ldz, float* __restrict__ sq, int rows, int p) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* z = Z + (long)row * ldz;
+    float s = 0.f;
+    for (int j = threadIdx.x & 63; j < p; j += 64) s = fmaf(z[j], z[j], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sq[row] = s;
+}
+
+// ---- error text (thread-local) ---------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace vgan
+
+using namespace vgan;
+
+extern "C" int vgan_abi_version(void) { return VGAN_ABI_VERSION; }
+extern "C" const char* vgan_last_error(void) { return g_err; }
+
+// Host-side tile table.  Single rank: symmetric blocks use the upper triangle only (TWICE + MIRROR);
+// the XY block is laid out with rows in the Y half and columns in the X half so that Wg ([n,2n],
+// wrow0 = n) needs no transposed store for it.  Row-sharded ranks cover (own rows) x (all columns).
+extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int32_t* out, int cap) {
+    if (n <= 0 || grad_mode < 0 || grad_mode > 2 || world < 1 || rank < 0 || rank >= world) {
+        set_error("vgan_mmd_build_tiles: bad argument");
+        return -1;
+    }
+    const int T = VGAN_TILE;
+    int count = 0;
+    auto emit = [&](int r0, int c0, int rlim, int clim, int flags) {
+        if (out != nullptr && count < cap) {
+            int32_t* e = out + (size_t)count * VGAN_TILE_INTS;
+            e[0] = r0; e[1] = c0; e[2] = rlim; e[3] = clim; e[4] = flags; e[5] = e[6] = e[7] = 0;
+        }
+        ++count;
+    };
+    if (world == 1) {
+        // XX: upper triangle; gradient rows only when grad_mode == 2
+        for (int r = 0; r < n; r += T)
+            for (int c = r; c < n; c += T) {
+                int fl = 0 | (c > r ? VGAN_TF_TWICE : 0);
+                if (grad_mode == 2) fl |= VGAN_TF_STORE | (c > r ? VGAN_TF_MIRROR : 0);
+                emit(r, c, n, n, fl);
+            }
+        // XY: rows in Y, columns in X (full block)
+        for (int r = 0; r < n; r += T)
+            for (int c = 0; c < n; c += T) {
+                int fl = 1 | VGAN_TF_NEG;
+                if (grad_mode >= 1) fl |= VGAN_TF_STORE;
+                if (grad_mode == 2) fl |= VGAN_TF_MIRROR;
+                emit(n + r, c, 2 * n, n, fl);
+            }
+        // YY: upper triangle
+        for (int r = 0; r < n; r += T)
+            for (int c = r; c < n; c += T) {
+                int fl = 2 | (c > r ? VGAN_TF_TWICE : 0);
+                if (grad_mode >= 1) fl |= VGAN_TF_STORE | (c > r ? VGAN_TF_MIRROR : 0);
+                emit(n + r, n + c, 2 * n, 2 * n, fl);
+            }
+    } else {
+        // rank owns rows [lo, hi) of each half; Wg (if any) holds its own rows only:
+        //   grad_mode 1: Wg [hi-lo, 2n], wrow0 = n + lo ; grad_mode 2 is not sharded (caller error).
+        if (grad_mode == 2) {
+            set_error("vgan_mmd_build_tiles: grad_mode 2 is not available row-sharded");
+            return -1;
+        }
+        const int lo = (int)((long)n * rank / world), hi = (int)((long)n * (rank + 1) / world);
+        for (int r = lo; r < hi; r += T)
+            for (int c = 0; c < n; c += T) emit(r, c, hi, n, 0);  // XX rows (sums only)
+        for (int r = lo; r < hi; r += T)
+            for (int c = 0; c < n; c += T) emit(n + r, c, n + hi, n, 1 | VGAN_TF_NEG | (grad_mode ? VGAN_TF_STORE : 0));
+        for (int r = lo; r < hi; r += T)
+            for (int c = 0; c < n; c += T) emit(n + r, n + c, n + hi, 2 * n, 2 | (grad_mode ? VGAN_TF_STORE : 0));
+    }
+    if (out != nullptr && count > cap) return -1;
+    return count;
+}
+
+extern "C" int vgan_mmd_gram(const float* Z, int ldz, const float* sq, int n, int p, const float* bw, const int32_t* tiles,
+                             int ntiles, int calibrate, float* Wg, int ldw, int wrow0, float* partial, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(Z && sq && tiles && partial && n > 0 && p > 0 && ntiles > 0 && ldz >= p);
+    VGAN_CHECK_ARG(calibrate || bw);
+    VGAN_CHECK_ARG((reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const TileDesc* td = reinterpret_cast<const TileDesc*>(tiles);
+    const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
+    dim3 grid(ntiles), block(kBlock);
+    if (calibrate) {
+        if (vec)
+            hipLaunchKernelGGL((mmd_gram_kernel<4, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
+        else
+            hipLaunchKernelGGL((mmd_gram_kernel<1, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((mmd_gram_kernel<4, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
+        else
+            hipLaunchKernelGGL((mmd_gram_kernel<1, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
+    }
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mmd_reduce(const float* partial, const int32_t* tiles, int ntiles, double* stats, int zero_first,
+                               vgan_stream_t stream) {
+    VGAN_CHECK_ARG(partial && tiles && stats && ntiles > 0);
+    hipLaunchKernelGGL(mmd_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, partial,
+                       reinterpret_cast<const TileDesc*>(tiles), ntiles, stats, zero_first);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mmd_set_bandwidth(const double* stats, int n, float* bw, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(stats && bw && n > 0);
+    hipLaunchKernelGGL(mmd_set_bandwidth_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, stats, n, bw);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mmd_loss(const double* stats, const uint64_t* colkey, int n, int d, float weight, float* loss,
+                             float* loss_accum, float accum_scale, uint64_t* step_counter, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(stats && loss && n > 0 && d > 0);
+    hipLaunchKernelGGL(mmd_loss_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, stats,
+                       reinterpret_cast<const unsigned long long*>(colkey), n, d, weight, loss, loss_accum, accum_scale,
+                       reinterpret_cast<unsigned long long*>(step_counter));
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr, int ncols, int p,
+                                 const float* mul, int ldmul, float* out, int ldo, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(Wg && Z && out && nr > 0 && ncols > 0 && p > 0 && ldw >= ncols && ldz >= p && ldo >= p && wrow0 >= 0 &&
+                   wrow0 + nr <= ncols);
+    VGAN_CHECK_ARG(mul == nullptr || ldmul >= p);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (ncols % 4 == 0) && (ldw % 4 == 0) && (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Wg) && aligned16(Z);
+    dim3 grid((p + GT - 1) / GT, (nr + GT - 1) / GT), block(kBlock);
+    if (vec)
+        hipLaunchKernelGGL(mmd_backward_kernel<4>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo);
+    else
+        hipLaunchKernelGGL(mmd_backward_kernel<1>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(Z && sq && rows > 0 && p > 0 && ldz >= p);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((rows + 3) / 4), dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, sq, rows, p);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}

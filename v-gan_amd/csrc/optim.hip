@@ -1,0 +1,142 @@
+// Adadelta over one flat parameter buffer, the Philox noise feed, and the detector's MSE term.
+// Reference ops replaced: torch.optim.Adadelta.step (src/vgan.py:567-568, :619; 207-210),
+// noise_tensor.normal_() (src/vgan.py:610, :270, :307), __distance(x, y, 'L2') (src/vgan.py:58-59).
+// All HBM-streaming: 16 B per lane, grid-stride over <= 2048 workgroups.
+#include "vgan_common.hpp"
+
+namespace vgan {
+
+__device__ __forceinline__ void adadelta_one(float& p, float g, float& v, float& a, float lr, float rho, float eps, float wd,
+                                             float gs) {
+    g = fmaf(wd, p, g * gs);
+    v = fmaf(rho, v, (1.f - rho) * g * g);
+    const float std = sqrtf(v + eps);
+    const float delta = sqrtf(a + eps) / std * g;
+    a = fmaf(rho, a, (1.f - rho) * delta * delta);
+    p = fmaf(-lr, delta, p);
+}
+
+__global__ __launch_bounds__(kBlock) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                         float* __restrict__ acc, long count, float lr, float rho, float eps,
+                                                         float wd, float gs, int vec) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const long nv = count >> 2;
+        for (long q = i; q < nv; q += stride) {
+            float4 pv = reinterpret_cast<float4*>(p)[q], gv = reinterpret_cast<const float4*>(g)[q];
+            float4 vv = reinterpret_cast<float4*>(sq)[q], av = reinterpret_cast<float4*>(acc)[q];
+            adadelta_one(pv.x, gv.x, vv.x, av.x, lr, rho, eps, wd, gs);
+            adadelta_one(pv.y, gv.y, vv.y, av.y, lr, rho, eps, wd, gs);
+            adadelta_one(pv.z, gv.z, vv.z, av.z, lr, rho, eps, wd, gs);
+            adadelta_one(pv.w, gv.w, vv.w, av.w, lr, rho, eps, wd, gs);
+            reinterpret_cast<float4*>(p)[q] = pv;
+            reinterpret_cast<float4*>(sq)[q] = vv;
+            reinterpret_cast<float4*>(acc)[q] = av;
+        }
+        i += nv << 2;  // tail
+        for (long q = i; q < count; q += stride) adadelta_one(p[q], g[q], sq[q], acc[q], lr, rho, eps, wd, gs);
+    } else {
+        for (long q = i; q < count; q += stride) adadelta_one(p[q], g[q], sq[q], acc[q], lr, rho, eps, wd, gs);
+    }
+}
+
+// Philox4x32-10 (Salmon et al., SC'11): counter = (index, stream_id), key = seed ^ step-derived words.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+__global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict__ z, long count, unsigned long long seed,
+                                                             const unsigned long long* __restrict__ step_counter,
+                                                             unsigned long long stream_id) {
+    const unsigned long long step = step_counter ? step_counter[0] : 0ull;
+    const long nq = (count + 3) >> 2;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        unsigned c[4] = {(unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)step, (unsigned)(step >> 32)};
+        philox4x32_10(c, (unsigned)seed ^ (unsigned)stream_id, (unsigned)(seed >> 32) ^ (unsigned)(stream_id >> 32) ^ 0x5bd1e995u);
+        float o[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // Box-Muller on two uniform pairs
+            const float r = sqrtf(-2.0f * logf(u01(c[2 * h])));
+            float sn, cs;
+            sincosf(6.283185307179586f * u01(c[2 * h + 1]), &sn, &cs);
+            o[2 * h] = r * cs;
+            o[2 * h + 1] = r * sn;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < count) z[4 * q + e] = o[e];
+    }
+}
+
+// out[0] (+)= scale * sum((a-b)^2)
+__global__ __launch_bounds__(kBlock) void mse_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int n,
+                                                    int d, float scale, float* __restrict__ out, int accumulate) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const long total = (long)n * d;
+    for (long idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int i = (int)(idx / d), j = (int)(idx % d);
+        const float df = a[(long)i * lda + j] - b[(long)i * ldb + j];
+        s += (double)df * (double)df;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(((red[0] + red[1]) + (red[2] + red[3])) * (double)scale);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
+}  // namespace vgan
+
+using namespace vgan;
+
+static inline int stream_grid(long work_items) {
+    long g = (work_items + kBlock - 1) / kBlock;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+extern "C" int vgan_adadelta_step(float* p, const float* g, float* sq_avg, float* acc_delta, int64_t count, float lr, float rho,
+                                  float eps, float weight_decay, float grad_scale, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(p && g && sq_avg && acc_delta && count > 0);
+    const int vec = aligned16(p) && aligned16(g) && aligned16(sq_avg) && aligned16(acc_delta);
+    hipLaunchKernelGGL(adadelta_kernel, dim3(stream_grid(vec ? (count + 3) / 4 : count)), dim3(kBlock), 0, (hipStream_t)stream, p, g,
+                       sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale, vec);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_noise_normal(float* z, int64_t count, uint64_t seed, const uint64_t* step_counter, uint64_t stream_id,
+                                 vgan_stream_t stream) {
+    VGAN_CHECK_ARG(z && count > 0);
+    hipLaunchKernelGGL(noise_normal_kernel, dim3(stream_grid((count + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, z, (long)count,
+                       (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step_counter),
+                       (unsigned long long)stream_id);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mse(const float* a, int lda, const float* b, int ldb, int n, int d, float scale, float* out, int accumulate,
+                        vgan_stream_t stream) {
+    VGAN_CHECK_ARG(a && b && out && n > 0 && d > 0 && lda >= d && ldb >= d);
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, a, lda, b, ldb, n, d, scale, out, accumulate);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}

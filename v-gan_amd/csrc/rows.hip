@@ -1,0 +1,237 @@
+// Row-wise kernels of the V-GAN step: upper_softmax, the U * X projection, their backward, and the
+// column arg-max of U used by the feature-count penalty.
+// Reference ops replaced: src/models/Generator.py:18-22 (softmax, less/greater_equal, mul, add),
+// src/vgan.py:616 (`fake_subspaces * batch`), src/models/Mmd_loss_constrained.py:50 (topk(U,1,0)),
+// and the DataLoader batch gather (src/vgan.py:578-584, :599).
+//
+// All are HBM/L2-streaming kernels: one 64-lane wave per row, coalesced 256-byte wave accesses,
+// reductions by wave shuffles only (no LDS).
+#include "vgan_common.hpp"
+
+namespace vgan {
+
+constexpr int kRowsPerBlock = kBlock / kWave;  // 4 rows per workgroup, one per wave
+
+// S = softmax(logits row), U = S < 1/d ? S : 1, Y = U * X;  Z = [X ; Y], sq = row norms of Z.
+// Batch row table: the batch of step t is rows[(t % row_batches) * row_stride + row_offset + i], with t read from
+// the device-side step counter (so one captured HIP graph walks a whole epoch's shuffled batches).
+struct RowSel {
+    const int* rows;
+    const unsigned long long* cursor;
+    int row_batches, row_stride, row_offset;
+    __device__ __forceinline__ long operator()(int i) const {
+        if (rows == nullptr) return (long)(row_offset + i);
+        const long b = cursor ? (long)(cursor[0] % (unsigned long long)row_batches) : 0l;
+        return (long)rows[b * row_stride + row_offset + i];
+    }
+};
+
+template <bool PROJECT>
+__global__ __launch_bounds__(kBlock) void mask_forward_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
+                                                             int ldd, RowSel rows, float* __restrict__ S,
+                                                             float* __restrict__ U, float* __restrict__ Zx, float* __restrict__ Zy,
+                                                             int ldz, float* __restrict__ sqx, float* __restrict__ sqy, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* x = logits + (long)i * ldl;
+    float m = -INFINITY;
+    for (int j = lane; j < d; j += 64) m = fmaxf(m, x[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < d; j += 64) sum += expf(x[j] - m);
+    sum = wave_sum(sum);
+    const float tau = 1.0f / (float)d;  // float32(1/d), the threshold of Generator.py:20-21
+    const float* xr = nullptr;
+    float *zx = nullptr, *zy = nullptr;
+    if constexpr (PROJECT) {
+        const long src = rows(i);
+        xr = data + src * ldd;
+        zx = Zx ? Zx + (long)i * ldz : nullptr;
+        zy = Zy + (long)i * ldz;
+    }
+    float nx = 0.f, ny = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        const float s = expf(x[j] - m) / sum;
+        const float u = s < tau ? s : 1.0f;
+        S[(long)i * d + j] = s;
+        if (U) U[(long)i * d + j] = u;
+        if constexpr (PROJECT) {
+            const float xv = xr[j];
+            const float yv = u * xv;
+            if (zx) zx[j] = xv;
+            zy[j] = yv;
+            nx = fmaf(xv, xv, nx);
+            ny = fmaf(yv, yv, ny);
+        }
+    }
+    if constexpr (PROJECT) {
+        nx = wave_sum(nx);
+        ny = wave_sum(ny);
+        if (lane == 0) {
+            if (sqx) sqx[i] = nx;
+            sqy[i] = ny;
+        }
+    }
+}
+
+// dlogits = S * (g_s - sum_j g_s S),  g_s = [S < 1/d] * (gU + penalty gradient at the column arg-max row)
+__global__ __launch_bounds__(kBlock) void mask_backward_kernel(const float* __restrict__ gU, int ldg, const float* __restrict__ S,
+                                                              int lds, const unsigned long long* __restrict__ colkey,
+                                                              float pen_weight, int row_offset, float* __restrict__ dlogits,
+                                                              int ldo, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float tau = 1.0f / (float)d;
+    const float pg = -pen_weight / (float)d;
+    const float* g = gU + (long)i * ldg;
+    const float* s = S + (long)i * lds;
+    const unsigned me = (unsigned)(row_offset + i);
+    float dot = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        const float sv = s[j];
+        float gv = g[j];
+        if (colkey != nullptr && colkey_row(colkey[j]) == me) gv += pg;
+        dot = fmaf(sv < tau ? gv : 0.f, sv, dot);
+    }
+    dot = wave_sum(dot);
+    for (int j = lane; j < d; j += 64) {
+        const float sv = s[j];
+        float gv = g[j];
+        if (colkey != nullptr && colkey_row(colkey[j]) == me) gv += pg;
+        dlogits[(long)i * ldo + j] = sv * ((sv < tau ? gv : 0.f) - dot);
+    }
+}
+
+// column arg-max of U = (S < tau ? S : 1) over a chunk of rows: grid (ceil(d/64), chunks)
+constexpr int kColChunkRows = 64;
+__global__ __launch_bounds__(kBlock) void colmax_partial_kernel(const float* __restrict__ S, int lds, int row_offset,
+                                                               unsigned long long* __restrict__ part, int n, int d, int from_softmax) {
+    __shared__ unsigned long long red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * kColChunkRows;
+    const float tau = from_softmax ? 1.0f / (float)d : INFINITY;  // U given directly: no threshold
+    unsigned long long best = 0ull;
+    if (j < d) {
+        for (int r = r0 + wave; r < min(r0 + kColChunkRows, n); r += 4) {
+            const float sv = S[(long)r * lds + j];
+            const unsigned long long k = colkey_pack(sv < tau ? sv : 1.0f, (unsigned)(row_offset + r));
+            best = k > best ? k : best;
+        }
+    }
+    red[wave][lane] = best;
+    __syncthreads();
+    if (wave == 0 && j < d) {
+        unsigned long long b = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) b = red[w][lane] > b ? red[w][lane] : b;
+        part[(long)blockIdx.y * d + j] = b;
+    }
+}
+__global__ void colmax_final_kernel(const unsigned long long* __restrict__ part, int chunks, unsigned long long* __restrict__ colkey,
+                                    int d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    unsigned long long b = 0ull;
+    for (int c = 0; c < chunks; ++c) {
+        const unsigned long long k = part[(long)c * d + j];
+        b = k > b ? k : b;
+    }
+    colkey[j] = b;
+}
+
+// out[i] = data[rows[i]] with squared norms: the batch gather for rows whose mask another rank owns
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ data, int ldd, RowSel rows,
+                                                            float* __restrict__ out, int ldo, float* __restrict__ sq, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* x = data + rows(i) * ldd;
+    float* o = out + (long)i * ldo;
+    float nx = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        const float v = x[j];
+        o[j] = v;
+        nx = fmaf(v, v, nx);
+    }
+    nx = wave_sum(nx);
+    if (lane == 0 && sq) sq[i] = nx;
+}
+
+__global__ void mask_from_softmax_kernel(const float* __restrict__ S, int lds, float* __restrict__ U, int ldu, int n, int d) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * d) return;
+    const int i = (int)(idx / d), j = (int)(idx % d);
+    const float sv = S[(long)i * lds + j];
+    U[(long)i * ldu + j] = sv < 1.0f / (float)d ? sv : 1.0f;
+}
+
+}  // namespace vgan
+
+using namespace vgan;
+
+extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
+                                         const uint64_t* row_cursor, int row_batches, int row_stride, int row_offset, float* S,
+                                         float* U, float* Zx, float* Zy, int ldz, float* sqx, float* sqy, int n, int d,
+                                         vgan_stream_t stream) {
+    VGAN_CHECK_ARG(logits && data && S && Zy && sqy && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
+    VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && row_offset >= 0);
+    const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
+    hipLaunchKernelGGL(mask_forward_kernel<true>, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream,
+                       logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_upper_softmax_forward(const float* logits, int ldl, float* S, float* U, int n, int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(logits && S && n > 0 && d > 0 && ldl >= d);
+    hipLaunchKernelGGL(mask_forward_kernel<false>, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, logits, ldl, nullptr, 0, RowSel{nullptr, nullptr, 1, 0, 0}, S, U, nullptr, nullptr, 0, nullptr, nullptr, n, d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mask_backward(const float* gU, int ldg, const float* S, int lds, const uint64_t* colkey, float pen_weight,
+                                  int row_offset, float* dlogits, int ldo, int n, int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(gU && S && dlogits && n > 0 && d > 0 && ldg >= d && lds >= d && ldo >= d);
+    hipLaunchKernelGGL(mask_backward_kernel, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream, gU,
+                       ldg, S, lds, reinterpret_cast<const unsigned long long*>(colkey), pen_weight, row_offset, dlogits, ldo, n, d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_gather_rows(const float* data, int ldd, const int32_t* rows, const uint64_t* row_cursor, int row_batches,
+                                int row_stride, int row_offset, float* out, int ldo, float* sq, int n, int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(data && out && n > 0 && d > 0 && ldd >= d && ldo >= d && row_batches >= 1 && row_stride >= 0 && row_offset >= 0);
+    const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream, data,
+                       ldd, sel, out, ldo, sq, n, d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_colmax_chunks(int n) { return n > 0 ? (n + kColChunkRows - 1) / kColChunkRows : 0; }
+
+extern "C" int vgan_colmax(const float* S, int lds, int from_softmax, int row_offset, uint64_t* part, uint64_t* colkey, int n,
+                           int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(S && part && colkey && n > 0 && d > 0 && lds >= d);
+    const int chunks = vgan_colmax_chunks(n);
+    hipLaunchKernelGGL(colmax_partial_kernel, dim3((d + 63) / 64, chunks), dim3(kBlock), 0, (hipStream_t)stream, S, lds, row_offset,
+                       reinterpret_cast<unsigned long long*>(part), n, d, from_softmax);
+    VGAN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colmax_final_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(part), chunks, reinterpret_cast<unsigned long long*>(colkey), d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mask_from_softmax(const float* S, int lds, float* U, int ldu, int n, int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(S && U && n > 0 && d > 0 && lds >= d && ldu >= d);
+    const long total = (long)n * d;
+    hipLaunchKernelGGL(mask_from_softmax_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, lds, U,
+                       ldu, n, d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}

@@ -1,0 +1,68 @@
+// Shared device/host helpers for the V-GAN gfx950 kernels (CDNA4: 64-wide waves, fp32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vgan_hip.h"
+
+namespace vgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves, one per SIMD; two such workgroups per CU hide epilogues
+
+void set_error(const char* fmt, ...);
+
+#define VGAN_CHECK_ARG(cond)                                                        \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            ::vgan::set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); \
+            return VGAN_ERR_ARG;                                                    \
+        }                                                                           \
+    } while (0)
+
+#define VGAN_CHECK_LAUNCH()                                                                     \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) {                                                                 \
+            ::vgan::set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return VGAN_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// Column-max key: U > 0 always, so its IEEE bits order like the value; ties go to the LOWEST row.
+__device__ __forceinline__ unsigned long long colkey_pack(float u, unsigned row) {
+    return ((unsigned long long)__float_as_uint(u) << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+}
+__device__ __forceinline__ float colkey_value(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ unsigned colkey_row(unsigned long long k) { return 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace vgan

@@ -1,0 +1,85 @@
+"""ctypes binding of libvgan_hip.so (C ABI: include/vgan_hip.h).  Loading never touches the GPU;
+the library must exist -- there is no fallback."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvgan_hip.so")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); must list every function declared in include/vgan_hip.h
+SIGNATURES = {
+    "vgan_abi_version": (_i, []),
+    "vgan_last_error": (ctypes.c_char_p, []),
+    "vgan_linear_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "vgan_linear_backward_input": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
+    "vgan_gather_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
+    "vgan_mask_backward": (_i, [_p, _i, _p, _i, _p, _f, _i, _p, _i, _i, _i, _p]),
+    "vgan_colmax_chunks": (_i, [_i]),
+    "vgan_colmax": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p]),
+    "vgan_mask_from_softmax": (_i, [_p, _i, _p, _i, _i, _i, _p]),
+    "vgan_upper_softmax_forward": (_i, [_p, _i, _p, _p, _i, _i, _p]),
+    "vgan_mmd_build_tiles": (_i, [_i, _i, _i, _i, _p, _i]),
+    "vgan_mmd_gram": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _p, _p]),
+    "vgan_mmd_reduce": (_i, [_p, _p, _i, _p, _i, _p]),
+    "vgan_mmd_set_bandwidth": (_i, [_p, _i, _p, _p]),
+    "vgan_mmd_loss": (_i, [_p, _p, _i, _i, _f, _p, _p, _f, _p, _p]),
+    "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
+    "vgan_adadelta_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
+    "vgan_noise_normal": (_i, [_p, _i64, _u64, _p, _u64, _p]),
+    "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class VganHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VganHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C v-gan_amd/csrc`).  vgan_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vgan_abi_version() != ABI_VERSION:
+        raise VganHipError(f"ABI mismatch: library {lib.vgan_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().vgan_last_error().decode(errors="replace")
+        raise VganHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def build_tiles(n, grad_mode, rank=0, world=1):
+    """Host-side tile table of the Gram kernel as a flat list of int32 (8 per tile)."""
+    lib = load()
+    cnt = lib.vgan_mmd_build_tiles(n, grad_mode, rank, world, None, 0)
+    if cnt < 0:
+        raise VganHipError("vgan_mmd_build_tiles: " + lib.vgan_last_error().decode())
+    buf = (ctypes.c_int32 * (cnt * 8))()
+    got = lib.vgan_mmd_build_tiles(n, grad_mode, rank, world, ctypes.cast(buf, ctypes.c_void_p), cnt)
+    if got != cnt:
+        raise VganHipError("vgan_mmd_build_tiles: inconsistent tile count")
+    return list(buf), cnt

@@ -1,0 +1,188 @@
+"""Kernel provider: the one place that turns torch tensors into C-ABI calls (include/vgan_hip.h).
+
+``HipOps`` is the product's only provider.  Every method launches asynchronously on torch's
+current HIP stream (so calls can be captured into a HIP graph) and writes into caller-owned
+tensors.  A provider with the same method set over CPU tensors exists only under ``tests/`` to
+exercise the host logic (fit loop, sharding, collectives) without a GPU.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+_f32 = torch.float32
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _mat(t, name):
+    if not (t.is_cuda and t.dtype == _f32 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError(f"{name}: need a float32 HIP matrix with unit inner stride, got "
+                         f"{t.dtype} {tuple(t.shape)} strides {t.stride()} on {t.device}")
+    return t
+
+
+def _vec(t, name, dtype=_f32):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name}: need a contiguous {dtype} HIP tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+class HipOps:
+    """libvgan_hip.so on the current device/stream.  Raises if the library or a GPU is missing."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.VganHipError("vgan_amd needs a HIP device (torch.cuda.is_available() is False); "
+                                    "there is no CPU fallback")
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- host helpers -----------------------------------------------------------------------
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None):
+        flat, cnt = _lib.build_tiles(n, grad_mode, rank, world)
+        return torch.tensor(flat, dtype=torch.int32).view(cnt, 8).to(device or "cuda")
+
+    def colmax_chunks(self, n):
+        return self.lib.vgan_colmax_chunks(n)
+
+    # ---- Linear ------------------------------------------------------------------------------
+    def linear_forward(self, x, W, b, y):
+        _mat(x, "x"), _mat(W, "W"), _mat(y, "y")
+        n, kin = x.shape
+        out = W.shape[0]
+        assert W.shape[1] == kin and y.shape == (n, out)
+        _lib.check(self.lib.vgan_linear_forward(_ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), _ptr(y), y.stride(0),
+                                                n, kin, out, self._stream()), "vgan_linear_forward")
+
+    def linear_backward_input(self, dy, W, dx):
+        _mat(dy, "dy"), _mat(W, "W"), _mat(dx, "dx")
+        n, out = dy.shape
+        kin = W.shape[1]
+        assert W.shape[0] == out and dx.shape == (n, kin)
+        _lib.check(self.lib.vgan_linear_backward_input(_ptr(dy), dy.stride(0), _ptr(W), W.stride(0), _ptr(dx), dx.stride(0),
+                                                       n, kin, out, self._stream()), "vgan_linear_backward_input")
+
+    def linear_backward_params(self, dy, x, dW, db):
+        _mat(dy, "dy"), _mat(x, "x"), _mat(dW, "dW")
+        n, out = dy.shape
+        kin = x.shape[1]
+        assert x.shape[0] == n and dW.shape == (out, kin)
+        _lib.check(self.lib.vgan_linear_backward_params(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dW), dW.stride(0),
+                                                        _ptr(db), n, kin, out, self._stream()), "vgan_linear_backward_params")
+
+    # ---- upper_softmax / projection ------------------------------------------------------------
+    def mask_project_forward(self, logits, data, rows, S, U, Zx, Zy, sqx, sqy, row_cursor=None, row_batches=1, row_stride=0,
+                             row_offset=0):
+        _mat(logits, "logits"), _mat(data, "data"), _mat(Zy, "Zy")
+        n, d = logits.shape
+        assert S.is_contiguous() and S.shape == (n, d) and (U is None or (U.is_contiguous() and U.shape == (n, d)))
+        assert Zx is None or Zx.stride(0) == Zy.stride(0)
+        if rows is not None:
+            _vec(rows, "rows", torch.int32)
+        _lib.check(self.lib.vgan_mask_project_forward(_ptr(logits), logits.stride(0), _ptr(data), data.stride(0), _ptr(rows),
+                                                      _ptr(row_cursor), int(row_batches), int(row_stride), int(row_offset), _ptr(S), _ptr(U), _ptr(Zx), _ptr(Zy), Zy.stride(0), _ptr(sqx), _ptr(sqy),
+                                                      n, d, self._stream()), "vgan_mask_project_forward")
+
+    def gather_rows(self, data, rows, out, sq, row_cursor=None, row_batches=1, row_stride=0, row_offset=0):
+        _mat(data, "data"), _mat(out, "out")
+        n, d = out.shape[0], data.shape[1]
+        _lib.check(self.lib.vgan_gather_rows(_ptr(data), data.stride(0), _ptr(rows), _ptr(row_cursor), int(row_batches),
+                                             int(row_stride), int(row_offset), _ptr(out), out.stride(0), _ptr(sq), n, d,
+                                             self._stream()), "vgan_gather_rows")
+
+    def upper_softmax_forward(self, logits, S, U):
+        _mat(logits, "logits")
+        n, d = logits.shape
+        assert S.is_contiguous() and (U is None or U.is_contiguous())
+        _lib.check(self.lib.vgan_upper_softmax_forward(_ptr(logits), logits.stride(0), _ptr(S), _ptr(U), n, d, self._stream()),
+                   "vgan_upper_softmax_forward")
+
+    def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits):
+        _mat(gU, "gU"), _mat(S, "S"), _mat(dlogits, "dlogits")
+        n, d = S.shape
+        _lib.check(self.lib.vgan_mask_backward(_ptr(gU), gU.stride(0), _ptr(S), S.stride(0), _ptr(colkey), float(pen_weight),
+                                               int(row_offset), _ptr(dlogits), dlogits.stride(0), n, d, self._stream()),
+                   "vgan_mask_backward")
+
+    def colmax(self, S, row_offset, part, colkey, from_softmax=True):
+        _mat(S, "S")
+        n, d = S.shape
+        assert part.dtype == torch.int64 and colkey.dtype == torch.int64 and part.numel() >= self.colmax_chunks(n) * d
+        _lib.check(self.lib.vgan_colmax(_ptr(S), S.stride(0), int(bool(from_softmax)), int(row_offset), _ptr(part), _ptr(colkey), n, d, self._stream()),
+                   "vgan_colmax")
+
+    def mask_from_softmax(self, S, U):
+        _mat(S, "S"), _mat(U, "U")
+        n, d = S.shape
+        _lib.check(self.lib.vgan_mask_from_softmax(_ptr(S), S.stride(0), _ptr(U), U.stride(0), n, d, self._stream()),
+                   "vgan_mask_from_softmax")
+
+    # ---- MMD -------------------------------------------------------------------------------------
+    def row_sqnorm(self, Z, sq, p):
+        _mat(Z, "Z")
+        _lib.check(self.lib.vgan_row_sqnorm(_ptr(Z), Z.stride(0), _ptr(sq), Z.shape[0], int(p), self._stream()), "vgan_row_sqnorm")
+
+    def mmd_gram(self, Z, sq, n, p, bw, tiles, calibrate, Wg, wrow0, partial):
+        _mat(Z, "Z")
+        assert Z.shape[0] >= 2 * n and tiles.dtype == torch.int32 and tiles.is_contiguous()
+        ntiles = tiles.shape[0]
+        assert partial.numel() >= 4 * ntiles
+        ldw = Wg.stride(0) if Wg is not None else 0
+        _lib.check(self.lib.vgan_mmd_gram(_ptr(Z), Z.stride(0), _ptr(sq), int(n), int(p), _ptr(bw), _ptr(tiles), ntiles,
+                                          int(bool(calibrate)), _ptr(Wg), ldw, int(wrow0), _ptr(partial), self._stream()),
+                   "vgan_mmd_gram")
+
+    def mmd_reduce(self, partial, tiles, stats, zero_first=True):
+        assert stats.dtype == torch.float64 and stats.numel() >= 4
+        _lib.check(self.lib.vgan_mmd_reduce(_ptr(partial), _ptr(tiles), tiles.shape[0], _ptr(stats), int(bool(zero_first)),
+                                            self._stream()), "vgan_mmd_reduce")
+
+    def mmd_set_bandwidth(self, stats, n, bw):
+        _lib.check(self.lib.vgan_mmd_set_bandwidth(_ptr(stats), int(n), _ptr(bw), self._stream()), "vgan_mmd_set_bandwidth")
+
+    def mmd_loss(self, stats, colkey, n, d, weight, loss, loss_accum=None, accum_scale=1.0, step_counter=None):
+        _lib.check(self.lib.vgan_mmd_loss(_ptr(stats), _ptr(colkey), int(n), int(d), float(weight), _ptr(loss), _ptr(loss_accum),
+                                          float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_loss")
+
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out):
+        _mat(Wg, "Wg"), _mat(Z, "Z"), _mat(out, "out")
+        ldmul = mul.stride(0) if mul is not None else 0
+        _lib.check(self.lib.vgan_mmd_backward(_ptr(Wg), Wg.stride(0), _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(ncols), int(p),
+                                              _ptr(mul), ldmul, _ptr(out), out.stride(0), self._stream()), "vgan_mmd_backward")
+
+    # ---- optimiser / noise / misc ----------------------------------------------------------------
+    def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+        for t, nm in ((p, "p"), (g, "g"), (sq, "sq"), (acc, "acc")):
+            _vec(t, nm)
+        _lib.check(self.lib.vgan_adadelta_step(_ptr(p), _ptr(g), _ptr(sq), _ptr(acc), p.numel(), float(lr), float(rho), float(eps),
+                                               float(weight_decay), float(grad_scale), self._stream()), "vgan_adadelta_step")
+
+    def noise_normal(self, z, seed, step_counter, stream_id=0):
+        _vec(z, "z")
+        _lib.check(self.lib.vgan_noise_normal(_ptr(z), z.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(step_counter), int(stream_id),
+                                              self._stream()), "vgan_noise_normal")
+
+    def mse(self, a, b, scale, out, accumulate=False):
+        _mat(a, "a"), _mat(b, "b")
+        n, d = a.shape
+        _lib.check(self.lib.vgan_mse(_ptr(a), a.stride(0), _ptr(b), b.stride(0), n, d, float(scale), _ptr(out),
+                                     int(bool(accumulate)), self._stream()), "vgan_mse")
+
+
+_default = None
+
+
+def default_ops():
+    global _default
+    if _default is None:
+        _default = HipOps()
+    return _default

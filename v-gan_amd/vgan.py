@@ -1,0 +1,350 @@
+"""User surface: ``VGAN_no_kl`` and ``VGAN`` with the reference's constructor arguments, attributes
+and methods (reference: src/vgan.py:20-431 and :434-708), training on the MI355X kernels.
+
+``from src.vgan import VGAN, VGAN_no_kl`` (the notebook's import, test.ipynb:16) resolves to these
+classes through the ``src`` package at the repository root.
+"""
+import os
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from .modules import Decoder, Detector, Encoder, Generator_big, MMDLossConstrained
+from .ops import default_ops
+from .trainer import NoKLStepEngine
+
+
+def _device():
+    # src/vgan.py:46-47 picks cuda:0 -> mps:0 -> cpu; this build only runs on a HIP device
+    return torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+
+
+def epoch_batches(train_size, batch_size):
+    """Shuffled ``drop_last`` index batches of one epoch, drawn exactly as the reference's
+    ``DataLoader(X, batch_size, shuffle=True, drop_last=True)`` draws them (src/vgan.py:578-584):
+    iterating a DataLoader over the row indices consumes the default RNG in the same order."""
+    loader = DataLoader(torch.arange(train_size), batch_size=batch_size, drop_last=True, shuffle=True)
+    return torch.stack(list(loader))
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class _RunFolder:
+    """model_snapshot / get_params / plot: the reference's run-folder side outputs (src/vgan.py:80-140,
+    456-509).  Plain host code, same file names and CSV layout."""
+
+    def _plot_loss(self, path_to_directory, with_detector):
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:  # plotting is a convenience; training must not depend on it
+            return
+        generator_y = self.train_history["generator_loss"]
+        x = np.linspace(1, len(generator_y), len(generator_y))
+        fig, ax = plt.subplots()
+        ax.plot(x, generator_y, color="cornflowerblue", label="Generator loss", linewidth=2)
+        if with_detector:
+            ax.plot(x, self.train_history["detector_loss"], color="black", label="Detector loss", linewidth=2)
+        plt.xlabel("Epoch")
+        plt.ylabel("Loss")
+        ax.legend(loc="upper right")
+        plt.savefig(Path(path_to_directory) / "train_history.pdf", format="pdf", dpi=1200)
+        plt.close(fig)
+
+    def model_snapshot(self, path_to_directory=None, run_number=0, show=False):
+        import pandas as pd
+        if path_to_directory is None:
+            path_to_directory = self.path_to_directory
+        path_to_directory = Path(path_to_directory)
+        os.makedirs(path_to_directory / "train_history", exist_ok=True)
+        pd.DataFrame(self.train_history["generator_loss"]).to_csv(
+            path_to_directory / "train_history" / f"generator_loss_{run_number}.csv", header=False, index=False)
+        if not os.path.isfile(path_to_directory / "params.csv"):
+            pd.DataFrame(self.get_params(), [0]).to_csv(path_to_directory / "params.csv")
+        else:
+            params = pd.read_csv(path_to_directory / "params.csv", index_col=0)
+            params_new = pd.DataFrame(self.get_params(), [run_number])
+            params = params.reindex(params.index.union(params_new.index))
+            params.update(params_new)
+            params.to_csv(path_to_directory / "params.csv")
+        self._plot_loss(path_to_directory, with_detector=hasattr(self, "lr_D"))
+
+    def load_models(self, path_to_generator, ndims, device=None):
+        """src/vgan.py:142-158 / 511-527: restore a generator for sampling (state_dict keys main.N.*)."""
+        if device is None:
+            device = self.device
+        self.generator = Generator_big(img_size=ndims, latent_size=max(int(ndims / 16), 1)).to(device)
+        self.generator.load_state_dict(torch.load(path_to_generator, map_location=device, weights_only=True))
+        self.generator.eval()
+        self.generator_optimizer = f"Loaded Model from {path_to_generator} with {ndims} dimensions in the latent space"
+        self._latent_size = max(int(ndims / 16), 1)
+
+    def generate_subspaces(self, nsubs):
+        """src/vgan.py:355-370 / 639-647: seeded CPU noise -> generator -> bool mask ``u >= 1/d``."""
+        noise_tensor = torch.Tensor(nsubs, self._latent_size).to("cpu")
+        if self.seed is not None:
+            torch.manual_seed(self.seed)
+        noise_tensor.normal_()
+        with torch.no_grad():
+            u = self.generator(noise_tensor.to(self.device))
+        return torch.greater_equal(u, 1 / u.shape[1])
+
+    def sample(self, nsubs):
+        """Alias of generate_subspaces (BASELINE.json's north_star calls it sample())."""
+        return self.generate_subspaces(nsubs)
+
+    def approx_subspace_dist(self, subspace_count=500, add_leftover_features=False):
+        """src/vgan.py:372-382 / 649-659."""
+        u = self.generate_subspaces(subspace_count)
+        unique_subspaces, proba = np.unique(np.array(u.to("cpu")), axis=0, return_counts=True)
+        if (unique_subspaces.sum(axis=0) < 1).sum() != 0 and add_leftover_features:
+            unique_subspaces = np.append(unique_subspaces, [unique_subspaces.sum(axis=0) < 1], axis=0)
+            proba = np.append(proba / proba.sum(), 1)
+        self.subspaces = unique_subspaces
+        self.proba = proba / proba.sum()
+
+    def check_if_myopic(self, x_data, bandwidth=0.01, count=500):
+        raise NotImplementedError(
+            "check_if_myopic (src/vgan.py:384-431) rests on torch-two-sample's permutation test, which is not part "
+            "of the reference checkout and is unpinned; it is outside this build's hot-path scope (SURVEY.md 8f rank 2)")
+
+    def _save_run(self, generator, detector_too):
+        path_to_directory = Path(self.path_to_directory)
+        os.makedirs(path_to_directory / "models", exist_ok=True)
+        files = len(os.listdir(path_to_directory / "models"))
+        run_number = int(files / 2) if detector_too else int(files)
+        torch.save(generator.state_dict(), path_to_directory / "models" / f"generator_{run_number}.pt")
+        if detector_too:  # the reference writes the GENERATOR's state under the detector's name (src/vgan.py:348-349)
+            torch.save(generator.state_dict(), path_to_directory / "models" / f"detector_{run_number}.pt")
+        self.model_snapshot(path_to_directory, run_number, show=True)
+
+
+class VGAN_no_kl(_RunFolder):
+    """V-GAN without kernel learning (reference: src/vgan.py:434-708).  Same constructor defaults."""
+
+    def __init__(self, batch_size=500, epochs=2000, lr=0.007, momentum=0.99, seed=777, weight_decay=0.04, path_to_directory=None):
+        self.storage = locals()
+        self.train_history = defaultdict(list)
+        self.batch_size = batch_size
+        self.epochs = epochs
+        self.lr = lr
+        self.momentum = momentum  # stored, never used -- as in the reference (src/vgan.py:448)
+        self.seed = seed
+        self.weight_decay = weight_decay
+        self.path_to_directory = path_to_directory
+        self.generator_optimizer = None
+        self.device = _device()
+        # build-specific knobs (not constructor arguments, so the reference signature is unchanged)
+        self.noise_source = "device"   # "device": Philox on the GPU; "host": torch CPU generator (reference CPU-path RNG order)
+        self.use_graph = True
+        self.verbose = True
+
+    def get_params(self):
+        return {"batch size": self.batch_size, "epochs": self.epochs, "lr_g": self.lr, "momentum": self.momentum,
+                "weight decay": self.weight_decay, "batch_size": self.batch_size, "seed": self.seed,
+                "generator optimizer": self.generator_optimizer}
+
+    def get_the_networks(self, ndims, latent_size, device=None):
+        if device is None:
+            device = self.device
+        return Generator_big(img_size=ndims, latent_size=latent_size).to(device)
+
+    def _make_engine(self, generator, data, batches_per_epoch, loss_function):
+        rank, world = _dist_info()
+        eng = NoKLStepEngine(self._ops(), generator, data, self.batch_size, batches_per_epoch, lr=self.lr,
+                             weight_decay=self.weight_decay, penalty_weight=loss_function.weight, seed=self.seed or 0,
+                             noise=self.noise_source, rank=rank, world=world, use_graph=self.use_graph)
+        shared = loss_function.kernel.bandwidth  # the process-wide RBF may already be calibrated (reference quirk)
+        if shared is not None:
+            eng.set_bandwidth(float(shared))
+        return eng
+
+    def _ops(self):
+        return getattr(self, "_ops_override", None) or default_ops()
+
+    def fit(self, X):
+        """src/vgan.py:546-637.  X: [Ntrain, d] array-like.  Returns None; sets generator, bandwidth,
+        train_history['generator_loss'] (epoch means), batch_size = min(batch_size, Ntrain)."""
+        torch.manual_seed(self.seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(self.seed)
+
+        epochs = self.epochs
+        X = np.asarray(X) if not torch.is_tensor(X) else X
+        self._latent_size = latent_size = max(int(X.shape[1] / 16), 1)
+        ndims = X.shape[1]
+        train_size = X.shape[0]
+        self.batch_size = min(self.batch_size, train_size)
+        batches_per_epoch = train_size // self.batch_size
+
+        device = self.device
+        # the generator is initialised on the host with PyTorch's default Linear init (src/vgan.py:565-566),
+        # consuming the seeded CPU RNG exactly like the reference, then moved to the GPU
+        generator = Generator_big(img_size=ndims, latent_size=latent_size)
+        generator = generator.to(device)
+        self.generator_optimizer = "Adadelta"
+        loss_function = MMDLossConstrained(weight=10)  # src/vgan.py:571
+
+        data = torch.as_tensor(X).to(device=device, dtype=torch.float32).contiguous()  # resident in HBM for the whole fit
+        engine = self._make_engine(generator, data, batches_per_epoch, loss_function)
+        self._engine = engine
+
+        for epoch in range(epochs):
+            if self.verbose:
+                print(f"\rEpoch {epoch} of {epochs}")
+            engine.set_epoch_batches(epoch_batches(train_size, self.batch_size))
+            if self.noise_source == "host":
+                noise_tensor = torch.Tensor(self.batch_size, latent_size)  # src/vgan.py:594
+            for _ in range(batches_per_epoch):
+                if self.noise_source == "host":
+                    engine.set_noise(noise_tensor.normal_())  # src/vgan.py:610
+                engine.step()
+            generator_loss = engine.epoch_loss()  # the only host sync of the epoch
+            if loss_function.kernel.bandwidth is None:
+                loss_function.kernel.bandwidth = engine.bw.view(())
+            self.bandwidth = loss_function.kernel.bandwidth
+            if self.verbose:
+                print(f"Average loss in the epoch: {generator_loss}")
+            self.train_history["generator_loss"].append(generator_loss)
+
+        self.generator = generator
+        if self.path_to_directory is not None:
+            self._save_run(generator, detector_too=False)
+
+
+class VGAN(_RunFolder):
+    """V-GAN with kernel learning (reference: src/vgan.py:20-431): an auto-encoder "detector" in front of
+    the MMD, trained in alternation with the generator.  Runs module-by-module on the HIP operators
+    (Linear, upper_softmax, MMD) under autograd; see DESIGN.md for what is fused and what is not."""
+
+    def __init__(self, batch_size=500, temperature=0, epochs=2000, lr_G=0.007, lr_D=0.007, iternum_d=1, iternum_g=5,
+                 momentum=0.99, seed=777, weight_decay=0.04, path_to_directory=None):
+        self.storage = locals()
+        self.train_history = defaultdict(list)
+        self.batch_size = batch_size
+        self.temperature = temperature
+        self.epochs = epochs
+        self.lr_G = lr_G
+        self.lr_D = lr_D
+        self.iternum_d = iternum_d
+        self.iternum_g = iternum_g
+        self.momentum = momentum
+        self.weight_decay = weight_decay
+        self.path_to_directory = path_to_directory
+        self.generator_optimizer = None
+        self.device = _device()
+        self.seed = 777  # the reference overrides the constructor's seed (src/vgan.py:48)
+        self.verbose = True
+
+    def get_params(self):
+        return {"batch size": self.batch_size, "epochs": self.epochs, "lr_g": self.lr_G, "momentum": self.momentum,
+                "weight decay": self.weight_decay, "batch_size": self.batch_size, "seed": self.seed,
+                "generator optimizer": self.generator_optimizer}
+
+    @staticmethod
+    def _weights_init(m):
+        # src/vgan.py:69-78: Linear weights ~ N(0, 0.1), bias 0
+        if m.__class__.__name__.find("Linear") != -1:
+            m.weight.data.normal_(0.0, 0.1)
+            m.bias.data.fill_(0)
+
+    def get_the_networks(self, ndims, latent_size, device=None):
+        if device is None:
+            device = self.device
+        generator = Generator_big(img_size=ndims, latent_size=latent_size).to(device)
+        detector = Detector(latent_size, ndims, Encoder, Decoder).to(device)
+        return generator, detector
+
+    def fit(self, X):
+        """src/vgan.py:178-353: 1 detector epoch, then 5 generator epochs, repeating."""
+        torch.manual_seed(self.seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(self.seed)
+        X = np.asarray(X) if not torch.is_tensor(X) else X
+        self._latent_size = latent_size = max(int(X.shape[1] / 16), 1)
+        ndims = X.shape[1]
+        train_size = X.shape[0]
+        self.batch_size = min(self.batch_size, train_size)
+        device = self.device
+
+        generator = Generator_big(img_size=ndims, latent_size=latent_size)
+        detector = Detector(latent_size, ndims, Encoder, Decoder)
+        generator.apply(self._weights_init)
+        detector.apply(self._weights_init)
+        generator, detector = generator.to(device), detector.to(device)
+
+        gen_optimizer = torch.optim.Adadelta(generator.parameters(), lr=self.lr_G, weight_decay=self.weight_decay)
+        det_optimizer = torch.optim.Adadelta(detector.parameters(), lr=self.lr_D, weight_decay=self.weight_decay)
+        self.generator_optimizer = gen_optimizer.__class__.__name__
+        self.detector_optimizer = det_optimizer.__class__.__name__
+        loss_function = MMDLossConstrained(weight=self.temperature)
+
+        data = torch.as_tensor(X).to(device=device, dtype=torch.float32).contiguous()
+        batch_number = train_size // self.batch_size
+        iternum_d = iternum_g = 1
+        detector_loss = generator_loss = np.nan
+        mse = lambda a, b: (a - b).pow(2).mean()  # __distance(x, y, 'L2'), src/vgan.py:58-59
+
+        for epoch in range(self.epochs):
+            if self.verbose:
+                print(f"\rEpoch {epoch} of {self.epochs}")
+            noise_tensor = torch.Tensor(self.batch_size, latent_size)
+            if iternum_d <= self.iternum_d:
+                acc = torch.zeros((), device=device)
+                for idx in epoch_batches(train_size, self.batch_size):
+                    batch = data[idx.to(device)]
+                    for p in detector.decoder.parameters():
+                        p.requires_grad = True
+                    batch_enc, batch_dec = detector(batch)
+                    with torch.no_grad():
+                        fake_subspaces = generator(noise_tensor.normal_().to(device)).clone().detach()
+                    projected = fake_subspaces * batch
+                    projected_enc, projected_dec = detector(projected)
+                    det_optimizer.zero_grad()
+                    batch_loss_D = -1 * (loss_function(batch_enc, projected_enc, fake_subspaces)
+                                         - .1 * mse(batch, batch_dec) - .1 * mse(projected, projected_dec))
+                    self.bandwidth = loss_function.bandwidth
+                    batch_loss_D.backward()
+                    det_optimizer.step()
+                    acc += batch_loss_D.detach() / batch_number
+                detector_loss = float(acc)
+                iternum_d += 1
+                iternum_g = 1
+            elif iternum_g <= self.iternum_g:
+                acc = torch.zeros((), device=device)
+                for idx in epoch_batches(train_size, self.batch_size):
+                    batch = data[idx.to(device)]
+                    batch_enc, batch_dec = detector(batch)
+                    fake_subspaces = generator(noise_tensor.normal_().to(device))
+                    projected_enc, projected_dec = detector(fake_subspaces * batch)
+                    for p in detector.parameters():  # src/vgan.py:319-320: freezes the detector for good
+                        p.requires_grad = False
+                    gen_optimizer.zero_grad()
+                    batch_loss_G = loss_function(batch_enc, projected_enc, fake_subspaces)
+                    self.bandwidth = loss_function.bandwidth
+                    batch_loss_G.backward()
+                    gen_optimizer.step()
+                    acc += batch_loss_G.detach() / batch_number
+                generator_loss = float(acc)
+                iternum_g += 1
+                if iternum_g > self.iternum_g:
+                    iternum_d = 1
+            if self.verbose:
+                print(f"Average loss in the epoch Generator: {generator_loss}")
+                print(f"Average loss in the epoch Detector: {detector_loss}")
+            self.train_history["generator_loss"].append(generator_loss)
+            self.train_history["detector_loss"].append(detector_loss)
+
+        self.generator = generator
+        self.detector = detector
+        if self.path_to_directory is not None:
+            self._save_run(generator, detector_too=True)
