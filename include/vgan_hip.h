@@ -45,10 +45,16 @@ int vgan_linear_forward(const float* x, int ldx, const float* W, int ldw, const 
 /* dx[n,in] = dy[n,out] . W */
 int vgan_linear_backward_input(const float* dy, int lddy, const float* W, int ldw,
                                float* dx, int lddx, int n, int in, int out, vgan_stream_t stream);
-/* dW[out,in] = dy^T . x ;  db[out] = column sums of dy   (db may be NULL) */
+/* dW[out,in] = dy^T . x ;  db[out] = column sums of dy   (db may be NULL).
+ * splits > 1: the batch rows are cut into `splits` slices and slice s writes its PARTIAL result to
+ * dW + s*slab_stride / db + s*slab_stride (elements); sum the slabs with vgan_reduce_slabs.  The
+ * contraction runs over the batch while the outputs are small, so slicing is what fills the chip. */
 int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx,
                                 float* dW, int lddw, float* db, int n, int in, int out,
-                                vgan_stream_t stream);
+                                int splits, int64_t slab_stride, vgan_stream_t stream);
+/* dst[i] = sum over s < nslabs of src[s*slab_stride + i], in ascending s (bitwise reproducible) */
+int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nslabs, float* dst, int64_t count,
+                      vgan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * upper_softmax + projection  (src/models/Generator.py:18-22, src/vgan.py:616 `U * batch`)

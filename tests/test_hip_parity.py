@@ -52,6 +52,17 @@ def test_linear_forward_backward(ops, n, kin, out):
     ref = dy.astype(np.float32).astype(np.float64).T @ x.astype(np.float32)
     np.testing.assert_allclose(host(dW), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
     np.testing.assert_allclose(host(db), dy.astype(np.float32).astype(np.float64).sum(0), rtol=0, atol=2e-5 * np.abs(dy).sum(0).max())
+    # split-K slabs over the batch rows + fixed-order reduction
+    for splits in (3, 8):
+        stride = (out * kin + out + 7) // 4 * 4
+        slab = torch.full((splits, stride), float("nan"), device="cuda")
+        dWs, dbs = slab[0, :out * kin].view(out, kin), slab[0, out * kin:out * kin + out]
+        ops.linear_backward_params(dyd, xd, dWs, dbs, splits, stride)
+        red = torch.empty(out * kin + out, device="cuda")
+        ops.reduce_slabs(slab, stride, splits, red)
+        np.testing.assert_allclose(host(red[:out * kin]).reshape(out, kin), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+        np.testing.assert_allclose(host(red[out * kin:]), dy.astype(np.float32).astype(np.float64).sum(0), rtol=0,
+                                   atol=2e-5 * np.abs(dy).sum(0).max())
 
 
 # ------------------------------------------------------------------------------ upper_softmax / projection

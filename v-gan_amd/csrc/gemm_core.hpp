@@ -18,6 +18,12 @@ enum : int { KC = 0, MC = 1 };  // KC: elem(mn,k) = p[mn*ld + k] ; MC: elem(mn,k
 
 constexpr int kPad = 4;  // row pad (floats): keeps ds_write_b128 aligned, transposing writes <= 2-way
 
+// LDS pointers carry their address space explicitly: through a generic `float*` (e.g. a runtime-selected
+// double-buffer pointer) hipcc emits flat_load/flat_store, which are slower than ds_read/ds_write AND count
+// on vmcnt, so every fragment read would also wait for the global prefetch in flight.
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) f32x4 lds_f4;  // ext-vector: plain assignment works in any address space
+
 // ---- global -> register -> LDS staging of one operand tile [BMN x BK] ----------------------
 template <int BMN, int BK, int LAYOUT, int VEC>
 struct Stager;
@@ -27,21 +33,26 @@ struct Stager<BMN, BK, KC, 4> {
     static constexpr int NV = BMN * BK / 4 / kBlock;
     static_assert(NV >= 1, "tile too small");
     float4 v[NV];
+    bool ok[NV];
+    // Loads are UNCONDITIONAL from a clamped (always valid) address and the out-of-range zeroing happens in
+    // store(): a guarded load compiles to a branch whose merge forces s_waitcnt vmcnt(0) right after issue,
+    // which would serialise the prefetch with the MFMAs it is meant to hide under.
     __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
-            int m = f / (BK / 4), kq = f % (BK / 4);
-            bool ok = (mn0 + m < MN) && (k0 + 4 * kq < K);
-            v[r] = ok ? *reinterpret_cast<const float4*>(p + (long)(mn0 + m) * ld + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+            int m = mn0 + f / (BK / 4), k = k0 + 4 * (f % (BK / 4));
+            ok[r] = (m < MN) && (k < K);
+            v[r] = *reinterpret_cast<const float4*>(p + (long)min(m, MN - 1) * ld + min(k, K - 4));
         }
     }
-    __device__ __forceinline__ void store(float* lds, int tid) const {
+    __device__ __forceinline__ void store(lds_f* lds, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
             int m = f / (BK / 4), kq = f % (BK / 4);
-            float* q = lds + (4 * kq) * (BMN + kPad) + m;
+            if (!ok[r]) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            lds_f* q = lds + (4 * kq) * (BMN + kPad) + m;
             q[0] = v[r].x;
             q[BMN + kPad] = v[r].y;
             q[2 * (BMN + kPad)] = v[r].z;
@@ -54,7 +65,7 @@ struct Stager<BMN, BK, KC, 4> {
 #pragma unroll
         for (int r = 0; r < NV; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
     }
-    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], float* /*scratch*/, float* out, int tid) {
+    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* /*scratch*/, lds_f* out, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             float t = (s[r].x + s[r].y) + (s[r].z + s[r].w);
@@ -70,20 +81,22 @@ template <int BMN, int BK>
 struct Stager<BMN, BK, KC, 1> {
     static constexpr int NV = BMN * BK / kBlock;
     float v[NV];
+    bool ok[NV];
     __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
-            int m = f / BK, k = f % BK;
-            bool ok = (mn0 + m < MN) && (k0 + k < K);
-            v[r] = ok ? p[(long)(mn0 + m) * ld + k0 + k] : 0.f;
+            int m = mn0 + f / BK, k = k0 + f % BK;
+            ok[r] = (m < MN) && (k < K);
+            v[r] = p[(long)min(m, MN - 1) * ld + min(k, K - 1)];
         }
     }
-    __device__ __forceinline__ void store(float* lds, int tid) const {
+    __device__ __forceinline__ void store(lds_f* lds, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
             int m = f / BK, k = f % BK;
+            if (!ok[r]) v[r] = 0.f;
             lds[k * (BMN + kPad) + m] = v[r];
         }
     }
@@ -92,7 +105,7 @@ struct Stager<BMN, BK, KC, 1> {
 #pragma unroll
         for (int r = 0; r < NV; ++r) s[r] += v[r];
     }
-    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], float* /*scratch*/, float* out, int tid) {
+    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* /*scratch*/, lds_f* out, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             float t = s[r];
@@ -109,21 +122,23 @@ struct Stager<BMN, BK, MC, 4> {
     static constexpr int NV = BMN * BK / 4 / kBlock;
     static_assert(NV >= 1, "tile too small");
     float4 v[NV];
+    bool ok[NV];
     __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
-            int k = f / (BMN / 4), mq = f % (BMN / 4);
-            bool ok = (k0 + k < K) && (mn0 + 4 * mq < MN);  // MN % 4 == 0 on this path
-            v[r] = ok ? *reinterpret_cast<const float4*>(p + (long)(k0 + k) * ld + mn0 + 4 * mq) : make_float4(0, 0, 0, 0);
+            int k = k0 + f / (BMN / 4), m = mn0 + 4 * (f % (BMN / 4));
+            ok[r] = (k < K) && (m < MN);  // MN % 4 == 0 on this path
+            v[r] = *reinterpret_cast<const float4*>(p + (long)min(k, K - 1) * ld + min(m, MN - 4));
         }
     }
-    __device__ __forceinline__ void store(float* lds, int tid) const {
+    __device__ __forceinline__ void store(lds_f* lds, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
             int k = f / (BMN / 4), mq = f % (BMN / 4);
-            *reinterpret_cast<float4*>(lds + k * (BMN + kPad) + 4 * mq) = v[r];
+            if (!ok[r]) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(lds_f4*)(lds + k * (BMN + kPad) + 4 * mq) = f32x4{v[r].x, v[r].y, v[r].z, v[r].w};
         }
     }
     typedef float4 Side;
@@ -132,13 +147,13 @@ struct Stager<BMN, BK, MC, 4> {
         for (int r = 0; r < NV; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
     }
     // every staged float4 of a thread has the same mq (kBlock % (BMN/4) == 0): fold r, then across threads via LDS
-    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], float* scratch, float* out, int tid) {
+    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* scratch, lds_f* out, int tid) {
         static_assert(kBlock % (BMN / 4) == 0, "mq must be fixed per thread");
         constexpr int ROWS = kBlock / (BMN / 4);
         float4 t = s[0];
 #pragma unroll
         for (int r = 1; r < NV; ++r) { t.x += s[r].x; t.y += s[r].y; t.z += s[r].z; t.w += s[r].w; }
-        *reinterpret_cast<float4*>(scratch + (tid / (BMN / 4)) * BMN + 4 * (tid % (BMN / 4))) = t;
+        *(lds_f4*)(scratch + (tid / (BMN / 4)) * BMN + 4 * (tid % (BMN / 4))) = f32x4{t.x, t.y, t.z, t.w};
         __syncthreads();
         if (tid < BMN) {
             float a = 0.f;
@@ -153,20 +168,22 @@ template <int BMN, int BK>
 struct Stager<BMN, BK, MC, 1> {
     static constexpr int NV = BMN * BK / kBlock;
     float v[NV];
+    bool ok[NV];
     __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
-            int k = f / BMN, m = f % BMN;
-            bool ok = (k0 + k < K) && (mn0 + m < MN);
-            v[r] = ok ? p[(long)(k0 + k) * ld + mn0 + m] : 0.f;
+            int k = k0 + f / BMN, m = mn0 + f % BMN;
+            ok[r] = (k < K) && (m < MN);
+            v[r] = p[(long)min(k, K - 1) * ld + min(m, MN - 1)];
         }
     }
-    __device__ __forceinline__ void store(float* lds, int tid) const {
+    __device__ __forceinline__ void store(lds_f* lds, int tid) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             int f = tid + kBlock * r;
             int k = f / BMN, m = f % BMN;
+            if (!ok[r]) v[r] = 0.f;
             lds[k * (BMN + kPad) + m] = v[r];
         }
     }
@@ -175,7 +192,7 @@ struct Stager<BMN, BK, MC, 1> {
 #pragma unroll
         for (int r = 0; r < NV; ++r) s[r] += v[r];
     }
-    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], float* scratch, float* out, int tid) {
+    __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* scratch, lds_f* out, int tid) {
         static_assert(kBlock % BMN == 0, "m must be fixed per thread");
         constexpr int ROWS = kBlock / BMN;
         float t = s[0];
@@ -205,14 +222,16 @@ struct GemmTile {
     // LDS buffers are reused as scratch for that reduction.
     template <bool SIDE_A>
     __device__ static __forceinline__ void run(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
-                                               int m0, int n0, int M, int N, int K, float* lds, float* side_lds,
+                                               int m0, int n0, int M, int N, int K, float* lds_generic, float* side_generic,
                                                f32x16 (&acc)[WM][WN]) {
+        lds_f* lds = (lds_f*)lds_generic;
+        lds_f* side_lds = (lds_f*)side_generic;
         const int tid = threadIdx.x;
         const int lane = tid & 63, wave = tid >> 6;
         const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
         const int fi = lane & 31, fh = lane >> 5;
-        float* sA[2] = {lds, lds + BK * SA};
-        float* sB[2] = {lds + 2 * BK * SA, lds + 2 * BK * SA + BK * SB};
+        lds_f* const sA0 = lds;                // buffers: A0 | A1 | B0 | B1
+        lds_f* const sB0 = lds + 2 * BK * SA;
 
         Stager<BM, BK, LA, VEC> ga;
         Stager<BN, BK, LB, VEC> gb;
@@ -226,8 +245,8 @@ struct GemmTile {
         const int nk = (K + BK - 1) / BK;
         ga.load(A, lda, m0, 0, M, K, tid);
         gb.load(B, ldb, n0, 0, N, K, tid);
-        ga.store(sA[0], tid);
-        gb.store(sB[0], tid);
+        ga.store(sA0, tid);  // store() also zeroes out-of-range values, so side_add after it sees masked data
+        gb.store(sB0, tid);
         if constexpr (SIDE_A) ga.side_add(side);
         __syncthreads();
 
@@ -238,8 +257,8 @@ struct GemmTile {
                 ga.load(A, lda, m0, (kt + 1) * BK, M, K, tid);
                 gb.load(B, ldb, n0, (kt + 1) * BK, N, K, tid);
             }
-            const float* a_base = sA[cur] + fh * SA + wm0 + fi;
-            const float* b_base = sB[cur] + fh * SB + wn0 + fi;
+            const lds_f* a_base = sA0 + cur * (BK * SA) + fh * SA + wm0 + fi;
+            const lds_f* b_base = sB0 + cur * (BK * SB) + fh * SB + wn0 + fi;
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 float a[WM], b[WN];
@@ -254,8 +273,8 @@ struct GemmTile {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             if (more) {
-                ga.store(sA[cur ^ 1], tid);
-                gb.store(sB[cur ^ 1], tid);
+                ga.store(sA0 + (cur ^ 1) * (BK * SA), tid);
+                gb.store(sB0 + (cur ^ 1) * (BK * SB), tid);
                 if constexpr (SIDE_A) ga.side_add(side);
             }
             __syncthreads();

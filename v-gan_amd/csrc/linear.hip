@@ -47,18 +47,33 @@ __global__ __launch_bounds__(kBlock, 2) void linear_bwd_input_kernel(const float
 }
 
 // dW = dy^T . x ; db = colsum(dy)    A(i=out, k=row) = dy[k*lddy + i] (MC), B(j=in, k=row) = x[k*ldx + j] (MC)
+// Split-K over the batch rows (blockIdx.z): the contraction length is the batch (1024) while the output is
+// small, so one launch needs the row range cut into `kchunk`-row slices to fill 256 CUs; slice s writes its
+// partial result into slab s (dW + s*slab_stride, db + s*slab_stride), summed afterwards by vgan_reduce_slabs
+// (fixed order: bitwise reproducible, no atomics).
 template <int VEC>
 __global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_kernel(const float* __restrict__ dy, int lddy,
                                                                      const float* __restrict__ x, int ldx, float* __restrict__ dW,
-                                                                     int lddw, float* __restrict__ db, int n, int in, int out) {
+                                                                     int lddw, float* __restrict__ db, int n, int in, int out,
+                                                                     int kchunk, long slab_stride) {
     using G = GemmTile<LBM, LBN, LBK, MC, MC, VEC>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float side[LBM];
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    const int k0 = blockIdx.z * kchunk;
+    const int klen = min(kchunk, n - k0);
+    dy += (long)k0 * lddy;
+    x += (long)k0 * ldx;
+    dW += blockIdx.z * slab_stride;
+    if (db != nullptr) db += blockIdx.z * slab_stride;
+    n = klen;
     f32x16 acc[G::WM][G::WN];
     zero_acc(acc);
     const bool do_bias = (db != nullptr) && (blockIdx.x == 0);
-    if (do_bias)
+    if (klen <= 0) {  // empty slice (more slabs than row slices): its slab is all zeros
+        if (threadIdx.x < LBM) side[threadIdx.x] = 0.f;
+        __syncthreads();
+    } else if (do_bias)
         G::template run<true>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc);
     else
         G::template run<false>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc);
@@ -104,16 +119,24 @@ extern "C" int vgan_linear_backward_input(const float* dy, int lddy, const float
 }
 
 extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, float* db,
-                                           int n, int in, int out, vgan_stream_t stream) {
+                                           int n, int in, int out, int splits, int64_t slab_stride, vgan_stream_t stream) {
     VGAN_CHECK_ARG(dy && x && dW && n > 0 && in > 0 && out > 0 && lddy >= out && ldx >= in && lddw >= in);
+    VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride > 0));
     hipStream_t s = (hipStream_t)stream;
+    // row slices are multiples of 4 rows so that every slice keeps the 16-byte alignment of the vector path
+    int kchunk = (n + splits - 1) / splits;
+    kchunk = (kchunk + 3) / 4 * 4;
+    const int nz = (n + kchunk - 1) / kchunk;
     const bool vec = (out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldx % 4 == 0) && aligned16(dy) && aligned16(x);
+    dim3 grid = grid_for(out, in);
+    grid.z = splits;  // slices beyond nz see klen <= 0 and write zeros, so the reducer may always sum `splits` slabs
+    (void)nz;
     if (vec)
-        hipLaunchKernelGGL(linear_bwd_params_kernel<4>, grid_for(out, in), dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in,
-                           out);
+        hipLaunchKernelGGL(linear_bwd_params_kernel<4>, grid, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in, out, kchunk,
+                           (long)slab_stride);
     else
-        hipLaunchKernelGGL(linear_bwd_params_kernel<1>, grid_for(out, in), dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in,
-                           out);
+        hipLaunchKernelGGL(linear_bwd_params_kernel<1>, grid, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in, out, kchunk,
+                           (long)slab_stride);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

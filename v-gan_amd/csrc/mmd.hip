@@ -5,6 +5,11 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <vector>
+
 #include "gemm_core.hpp"
 
 namespace vgan {
@@ -15,7 +20,7 @@ struct TileDesc {
 static_assert(sizeof(TileDesc) == VGAN_TILE_INTS * 4, "tile descriptor layout");
 
 constexpr int GT = VGAN_TILE;  // 64 x 64 Gram tile: one 32x32 MFMA sub-tile per wave
-constexpr int GBK = 16;
+constexpr int GBK = 32;  // 128-byte row segments per staging load (one full L2 line)
 
 // ---- Gram tile + fused kernel epilogue ----------------------------------------------------
 // CALIB: only sum of L (first-call bandwidth).  Otherwise: sum of K = t + t^2 + t^4 + t^8 + t^16 with
@@ -165,7 +170,17 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_backward_kernel(const float* __
     using G = GemmTile<GT, GT, GBK, KC, MC, VEC>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float rs[GT];
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    // XCD-aware tile order (speed only): block b runs on XCD b % 8; XCD x walks a contiguous chunk of a
+    // traversal that goes down 4 row panels, then to the next column panel, so the tiles resident on one
+    // XCD share their Wg row panels and Z column panels in its private L2.
+    const int gx = (p + GT - 1) / GT, gy = (nr + GT - 1) / GT, total = gx * gy;
+    const int xcd = blockIdx.x % 8, kidx = blockIdx.x / 8;
+    const int q = total / 8, r = total % 8;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kidx;
+    const int band = t / (4 * gx), rem = t - band * 4 * gx;
+    const int rows_in_band = min(4, gy - band * 4);
+    const int by = band * 4 + rem % rows_in_band, bx = rem / rows_in_band;
+    const int m0 = by * GT, n0 = bx * GT;
     f32x16 acc[1][1];
     zero_acc(acc);
     G::template run<true>(Wg, ldw, Z, ldz, m0, n0, nr, p, ncols, lds, rs, acc);
@@ -205,6 +220,31 @@ void set_error(const char* fmt, ...) {
 }  // namespace vgan
 
 using namespace vgan;
+
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD of b % 8), each with a private
+// 4 MiB L2.  Tiles that share a row or column panel of Z should therefore sit on ONE XCD: the table is
+// sorted along a Morton (Z-order) curve of the tile grid, cut into 8 contiguous chunks (compact, roughly
+// square footprints) and chunk x is placed at the table positions congruent to x mod 8.  Speed only:
+// any order gives the same sums (the reduction is by tile index, deterministic per table).
+static uint64_t morton_key(uint32_t r, uint32_t c) {
+    uint64_t k = 0;
+    for (int b = 0; b < 16; ++b) k |= ((uint64_t)((r >> b) & 1) << (2 * b + 1)) | ((uint64_t)((c >> b) & 1) << (2 * b));
+    return k;
+}
+static void order_tiles_for_xcds(int32_t* tiles, int count) {
+    constexpr int NX = 8;
+    std::vector<std::array<int32_t, VGAN_TILE_INTS>> v(count);
+    for (int t = 0; t < count; ++t) std::memcpy(v[t].data(), tiles + (size_t)t * VGAN_TILE_INTS, sizeof(int32_t) * VGAN_TILE_INTS);
+    std::stable_sort(v.begin(), v.end(), [](const auto& a, const auto& b) {
+        return morton_key(a[0] / VGAN_TILE, a[1] / VGAN_TILE) < morton_key(b[0] / VGAN_TILE, b[1] / VGAN_TILE);
+    });
+    const int q = count / NX, r = count % NX;
+    int src = 0;
+    for (int x = 0; x < NX; ++x) {
+        const int len = q + (x < r ? 1 : 0);
+        for (int k = 0; k < len; ++k, ++src) std::memcpy(tiles + (size_t)(k * NX + x) * VGAN_TILE_INTS, v[src].data(), sizeof(int32_t) * VGAN_TILE_INTS);
+    }
+}
 
 extern "C" int vgan_abi_version(void) { return VGAN_ABI_VERSION; }
 extern "C" const char* vgan_last_error(void) { return g_err; }
@@ -265,6 +305,7 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
             for (int c = 0; c < n; c += T) emit(n + r, n + c, n + hi, 2 * n, 2 | (grad_mode ? VGAN_TF_STORE : 0));
     }
     if (out != nullptr && count > cap) return -1;
+    if (out != nullptr) order_tiles_for_xcds(out, count);
     return count;
 }
 
@@ -325,7 +366,7 @@ extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int l
     VGAN_CHECK_ARG(mul == nullptr || ldmul >= p);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (ncols % 4 == 0) && (ldw % 4 == 0) && (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Wg) && aligned16(Z);
-    dim3 grid((p + GT - 1) / GT, (nr + GT - 1) / GT), block(kBlock);
+    dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT)), block(kBlock);
     if (vec)
         hipLaunchKernelGGL(mmd_backward_kernel<4>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo);
     else

@@ -41,6 +41,30 @@ __global__ __launch_bounds__(kBlock) void adadelta_kernel(float* __restrict__ p,
     }
 }
 
+// dst[i] = sum_s src[s*slab_stride + i], s ascending (fixed order)
+__global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const float* __restrict__ src, long slab_stride, int nslabs,
+                                                             float* __restrict__ dst, long count, int vec) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const long nv = count >> 2;
+        for (long q = i; q < nv; q += stride) {
+            float4 a = reinterpret_cast<const float4*>(src)[q];
+            for (int s = 1; s < nslabs; ++s) {
+                const float4 b = reinterpret_cast<const float4*>(src + s * slab_stride)[q];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            reinterpret_cast<float4*>(dst)[q] = a;
+        }
+        i += nv << 2;
+    }
+    for (long q = i; q < count; q += stride) {
+        float a = src[q];
+        for (int s = 1; s < nslabs; ++s) a += src[s * slab_stride + q];
+        dst[q] = a;
+    }
+}
+
 // Philox4x32-10 (Salmon et al., SC'11): counter = (index, stream_id), key = seed ^ step-derived words.
 __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
@@ -119,6 +143,15 @@ extern "C" int vgan_adadelta_step(float* p, const float* g, float* sq_avg, float
     const int vec = aligned16(p) && aligned16(g) && aligned16(sq_avg) && aligned16(acc_delta);
     hipLaunchKernelGGL(adadelta_kernel, dim3(stream_grid(vec ? (count + 3) / 4 : count)), dim3(kBlock), 0, (hipStream_t)stream, p, g,
                        sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale, vec);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nslabs, float* dst, int64_t count, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(src && dst && nslabs >= 1 && count > 0 && (nslabs == 1 || slab_stride >= count));
+    const int vec = aligned16(src) && aligned16(dst) && (slab_stride % 4 == 0);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(stream_grid(vec ? (count + 3) / 4 : count)), dim3(kBlock), 0, (hipStream_t)stream, src,
+                       (long)slab_stride, nslabs, dst, (long)count, vec);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

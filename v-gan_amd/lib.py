@@ -18,7 +18,8 @@ SIGNATURES = {
     "vgan_last_error": (ctypes.c_char_p, []),
     "vgan_linear_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_input": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
-    "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i64, _p]),
+    "vgan_reduce_slabs": (_i, [_p, _i64, _i, _p, _i64, _p]),
     "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
     "vgan_gather_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
     "vgan_mask_backward": (_i, [_p, _i, _p, _i, _p, _f, _i, _p, _i, _i, _i, _p]),

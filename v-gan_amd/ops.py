@@ -71,13 +71,20 @@ class HipOps:
         _lib.check(self.lib.vgan_linear_backward_input(_ptr(dy), dy.stride(0), _ptr(W), W.stride(0), _ptr(dx), dx.stride(0),
                                                        n, kin, out, self._stream()), "vgan_linear_backward_input")
 
-    def linear_backward_params(self, dy, x, dW, db):
+    def linear_backward_params(self, dy, x, dW, db, splits=1, slab_stride=0):
+        """splits > 1: dW/db are slab 0 of `splits` slabs `slab_stride` elements apart (partial sums)."""
         _mat(dy, "dy"), _mat(x, "x"), _mat(dW, "dW")
         n, out = dy.shape
         kin = x.shape[1]
         assert x.shape[0] == n and dW.shape == (out, kin)
         _lib.check(self.lib.vgan_linear_backward_params(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dW), dW.stride(0),
-                                                        _ptr(db), n, kin, out, self._stream()), "vgan_linear_backward_params")
+                                                        _ptr(db), n, kin, out, int(splits), int(slab_stride), self._stream()),
+                   "vgan_linear_backward_params")
+
+    def reduce_slabs(self, src, slab_stride, nslabs, dst):
+        _vec(dst, "dst")
+        _lib.check(self.lib.vgan_reduce_slabs(_ptr(src), int(slab_stride), int(nslabs), _ptr(dst), dst.numel(), self._stream()),
+                   "vgan_reduce_slabs")
 
     # ---- upper_softmax / projection ------------------------------------------------------------
     def mask_project_forward(self, logits, data, rows, S, U, Zx, Zy, sqx, sqy, row_cursor=None, row_batches=1, row_stride=0,

@@ -90,8 +90,13 @@ class NoKLStepEngine:
         self.fp = FlatParams(params, self.dev)
         self.W = [self.fp.view(self.fp.flat, 2 * k) for k in range(4)]
         self.b = [self.fp.view(self.fp.flat, 2 * k + 1) for k in range(4)]
-        self.dW = [self.fp.view(self.fp.grad, 2 * k) for k in range(4)]
-        self.db = [self.fp.view(self.fp.grad, 2 * k + 1) for k in range(4)]
+        # weight gradients contract over the batch rows: split that contraction into slabs so the launch fills
+        # the chip, then sum the slabs (fixed order) into the flat gradient
+        self.splits = max(1, min(8, (n // world) // 128))
+        self.gslab = torch.zeros(self.splits, self.fp.total, dtype=torch.float32, device=self.dev) if self.splits > 1 else None
+        gbase = self.gslab[0] if self.splits > 1 else self.fp.grad
+        self.dW = [self.fp.view(gbase, 2 * k) for k in range(4)]
+        self.db = [self.fp.view(gbase, 2 * k + 1) for k in range(4)]
 
         f32 = dict(dtype=torch.float32, device=self.dev)
         nl, dp = self.nl, self.dp
@@ -188,10 +193,12 @@ class NoKLStepEngine:
         ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits)
         g = self.dlogits
         for k in (3, 2, 1, 0):
-            ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k])
+            ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
             if k:
                 ops.linear_backward_input(g, self.W[k], self.dacts[k])
                 g = self.dacts[k]
+        if self.splits > 1:
+            ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
         if dist:
             dist.all_reduce(self.fp.grad, group=self.group)
         ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0)

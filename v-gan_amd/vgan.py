@@ -22,12 +22,43 @@ def _device():
     return torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
 
 
-def epoch_batches(train_size, batch_size):
-    """Shuffled ``drop_last`` index batches of one epoch, drawn exactly as the reference's
-    ``DataLoader(X, batch_size, shuffle=True, drop_last=True)`` draws them (src/vgan.py:578-584):
-    iterating a DataLoader over the row indices consumes the default RNG in the same order."""
+def _epoch_batches_dataloader(train_size, batch_size):
     loader = DataLoader(torch.arange(train_size), batch_size=batch_size, drop_last=True, shuffle=True)
     return torch.stack(list(loader))
+
+
+def _epoch_batches_direct(train_size, batch_size):
+    # what iterating that DataLoader draws from the default generator (torch/utils/data/dataloader.py
+    # `_BaseDataLoaderIter.__init__` -> base seed; sampler.py `RandomSampler.__iter__` -> seed of a private
+    # generator for randperm), without the per-batch collate overhead
+    torch.empty((), dtype=torch.int64).random_()
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    nb = train_size // batch_size
+    return torch.randperm(train_size, generator=g)[:nb * batch_size].view(nb, batch_size)
+
+
+_direct_ok = None
+
+
+def epoch_batches(train_size, batch_size):
+    """Shuffled ``drop_last`` index batches of one epoch [batches, batch_size], drawn exactly as the
+    reference's ``DataLoader(X, batch_size, shuffle=True, drop_last=True)`` draws them
+    (src/vgan.py:578-584), i.e. consuming torch's default CPU generator in the same order.  The
+    direct path is verified once per process against a real DataLoader from a forked RNG state; if
+    this torch version draws differently, the DataLoader itself is used."""
+    global _direct_ok
+    if _direct_ok is None:
+        with torch.random.fork_rng(devices=[]):
+            state = torch.random.get_rng_state()
+            a = _epoch_batches_dataloader(64, 8)
+            after_a = torch.random.get_rng_state()
+            torch.random.set_rng_state(state)
+            b = _epoch_batches_direct(64, 8)
+            _direct_ok = bool(torch.equal(a, b) and torch.equal(after_a, torch.random.get_rng_state()))
+    fn = _epoch_batches_direct if _direct_ok else _epoch_batches_dataloader
+    return fn(train_size, batch_size)
 
 
 def _dist_info():
