@@ -4,19 +4,28 @@
 // One workgroup = 256 threads = 4 waves laid out 2 (M) x 2 (N); each wave owns WM x WN
 // sub-tiles of 32x32 computed with v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 64 cycles per
 // issue per SIMD -- the fp32 matrix rate equals the fp32 vector peak on gfx950, so the MFMA
-// pipe, not LDS or L2, is the bound; staging is therefore kept simple: register-staged,
-// double-buffered LDS, one barrier per K tile, loads for tile t+1 issued before the MFMAs of t).
+// pipe, not LDS or L2, is the bound).  Staging is register-staged and double-buffered in LDS with
+// a three-stage pipeline (global loads two K tiles ahead, LDS fill one tile ahead), one barrier
+// per K tile.
 //
-// LDS image of both operands is [k][mn] (mn contiguous): the A/B fragment of the 32x32x2 MFMA is
-// lane l -> (mn = l & 31, k = l >> 5), so a fragment read is one conflict-free ds_read_b32.
+// LDS images never transpose on the way in (a transposing scalar store is a 4-way bank conflict that makes
+// the LDS, not the MFMA, the bound):
+//   KC operand (k contiguous in memory) -> image [mn][BK+4], filled by ds_write_b128, read by ds_read_b128;
+//   MC operand (mn contiguous in memory) -> image [BK][mn+4], filled by ds_write_b128, read by ds_read_b32.
+// The 32x32x2 MFMA takes lane l -> (mn = l & 31, k-slot = l >> 5).  Which k a slot carries is free as long as
+// A and B agree, so within each group of 8 k the step s (0..3) of half h = l >> 5 uses k = 8c + 4h + s: a KC
+// lane then needs exactly the 4 consecutive floats [8c + 4h, +4) of its row -- one 16-byte read per 4 MFMAs.
+// Row pads of 4 floats make every one of these accesses conflict-free (row stride = 4 * odd).
 #pragma once
+#include <type_traits>
+
 #include "vgan_common.hpp"
 
 namespace vgan {
 
 enum : int { KC = 0, MC = 1 };  // KC: elem(mn,k) = p[mn*ld + k] ; MC: elem(mn,k) = p[k*ld + mn]
 
-constexpr int kPad = 4;  // row pad (floats): keeps ds_write_b128 aligned, transposing writes <= 2-way
+constexpr int kPad = 4;  // row pad (floats)
 
 // LDS pointers carry their address space explicitly: through a generic `float*` (e.g. a runtime-selected
 // double-buffer pointer) hipcc emits flat_load/flat_store, which are slower than ds_read/ds_write AND count
@@ -25,6 +34,10 @@ typedef __attribute__((address_space(3))) float lds_f;
 typedef __attribute__((address_space(3))) f32x4 lds_f4;  // ext-vector: plain assignment works in any address space
 
 // ---- global -> register -> LDS staging of one operand tile [BMN x BK] ----------------------
+// init() hoists everything that does not depend on the K tile (row pointers, row validity, LDS offsets);
+// load(k0) issues UNCONDITIONAL loads from clamped, always-valid addresses and store() zeroes what was out
+// of range: a guarded load compiles to a branch whose merge forces s_waitcnt vmcnt(0) right after issue,
+// which would serialise the prefetch with the MFMAs it is meant to hide under.
 template <int BMN, int BK, int LAYOUT, int VEC>
 struct Stager;
 
@@ -33,30 +46,35 @@ struct Stager<BMN, BK, KC, 4> {
     static constexpr int NV = BMN * BK / 4 / kBlock;
     static_assert(NV >= 1, "tile too small");
     float4 v[NV];
-    bool ok[NV];
-    // Loads are UNCONDITIONAL from a clamped (always valid) address and the out-of-range zeroing happens in
-    // store(): a guarded load compiles to a branch whose merge forces s_waitcnt vmcnt(0) right after issue,
-    // which would serialise the prefetch with the MFMAs it is meant to hide under.
-    __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
+    const float* rowp[NV];
+    int lofs[NV];
+    bool rowok[NV], ok[NV];
+    int kq4, K;
+    __device__ __forceinline__ void init(const float* __restrict__ p, long ld, int mn0, int MN, int K_, int tid) {
+        K = K_;
+        kq4 = 4 * (tid % (BK / 4));  // kBlock % (BK/4) == 0: the same k offset for every r
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int m = mn0 + f / (BK / 4), k = k0 + 4 * (f % (BK / 4));
-            ok[r] = (m < MN) && (k < K);
-            v[r] = *reinterpret_cast<const float4*>(p + (long)min(m, MN - 1) * ld + min(k, K - 4));
+            const int m = (tid + kBlock * r) / (BK / 4);
+            rowok[r] = mn0 + m < MN;
+            rowp[r] = p + (long)min(mn0 + m, MN - 1) * ld;
+            lofs[r] = m * (BK + kPad) + kq4;
         }
     }
-    __device__ __forceinline__ void store(lds_f* lds, int tid) {
+    __device__ __forceinline__ void load(int k0) {
+        const int k = k0 + kq4;
+        const int kc = min(k, K - 4);
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int m = f / (BK / 4), kq = f % (BK / 4);
+            ok[r] = rowok[r] && (k < K);
+            v[r] = *reinterpret_cast<const float4*>(rowp[r] + kc);
+        }
+    }
+    __device__ __forceinline__ void store(lds_f* lds) {
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
             if (!ok[r]) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            lds_f* q = lds + (4 * kq) * (BMN + kPad) + m;
-            q[0] = v[r].x;
-            q[BMN + kPad] = v[r].y;
-            q[2 * (BMN + kPad)] = v[r].z;
-            q[3 * (BMN + kPad)] = v[r].w;
+            *(lds_f4*)(lds + lofs[r]) = f32x4{v[r].x, v[r].y, v[r].z, v[r].w};
         }
     }
     // side product: sum over k of the staged operand, per mn (rowsum of A / column sums for db)
@@ -81,23 +99,35 @@ template <int BMN, int BK>
 struct Stager<BMN, BK, KC, 1> {
     static constexpr int NV = BMN * BK / kBlock;
     float v[NV];
-    bool ok[NV];
-    __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
+    const float* rowp[NV];
+    int lofs[NV];
+    bool rowok[NV], ok[NV];
+    int kk, K;
+    __device__ __forceinline__ void init(const float* __restrict__ p, long ld, int mn0, int MN, int K_, int tid) {
+        K = K_;
+        kk = tid % BK;  // kBlock % BK == 0
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int m = mn0 + f / BK, k = k0 + f % BK;
-            ok[r] = (m < MN) && (k < K);
-            v[r] = p[(long)min(m, MN - 1) * ld + min(k, K - 1)];
+            const int m = (tid + kBlock * r) / BK;
+            rowok[r] = mn0 + m < MN;
+            rowp[r] = p + (long)min(mn0 + m, MN - 1) * ld;
+            lofs[r] = m * (BK + kPad) + kk;
         }
     }
-    __device__ __forceinline__ void store(lds_f* lds, int tid) {
+    __device__ __forceinline__ void load(int k0) {
+        const int k = k0 + kk;
+        const int kc = min(k, K - 1);
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int m = f / BK, k = f % BK;
+            ok[r] = rowok[r] && (k < K);
+            v[r] = rowp[r][kc];
+        }
+    }
+    __device__ __forceinline__ void store(lds_f* lds) {
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
             if (!ok[r]) v[r] = 0.f;
-            lds[k * (BMN + kPad) + m] = v[r];
+            lds[lofs[r]] = v[r];
         }
     }
     typedef float Side;
@@ -121,24 +151,38 @@ template <int BMN, int BK>
 struct Stager<BMN, BK, MC, 4> {
     static constexpr int NV = BMN * BK / 4 / kBlock;
     static_assert(NV >= 1, "tile too small");
+    static_assert(kBlock % (BMN / 4) == 0, "mq must be fixed per thread");
     float4 v[NV];
-    bool ok[NV];
-    __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
+    const float* colp;  // p + clamped column of this thread
+    long ld;
+    int krow[NV], lofs[NV];
+    bool colok, ok[NV];
+    int K;
+    __device__ __forceinline__ void init(const float* __restrict__ p, long ld_, int mn0, int MN, int K_, int tid) {
+        K = K_;
+        ld = ld_;
+        const int m = mn0 + 4 * (tid % (BMN / 4));  // MN % 4 == 0 on this path
+        colok = m < MN;
+        colp = p + min(m, MN - 4);
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int k = k0 + f / (BMN / 4), m = mn0 + 4 * (f % (BMN / 4));
-            ok[r] = (k < K) && (m < MN);  // MN % 4 == 0 on this path
-            v[r] = *reinterpret_cast<const float4*>(p + (long)min(k, K - 1) * ld + min(m, MN - 4));
+            krow[r] = (tid + kBlock * r) / (BMN / 4);
+            lofs[r] = krow[r] * (BMN + kPad) + 4 * (tid % (BMN / 4));
         }
     }
-    __device__ __forceinline__ void store(lds_f* lds, int tid) {
+    __device__ __forceinline__ void load(int k0) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int k = f / (BMN / 4), mq = f % (BMN / 4);
+            const int k = k0 + krow[r];
+            ok[r] = colok && (k < K);
+            v[r] = *reinterpret_cast<const float4*>(colp + (long)min(k, K - 1) * ld);
+        }
+    }
+    __device__ __forceinline__ void store(lds_f* lds) {
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
             if (!ok[r]) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            *(lds_f4*)(lds + k * (BMN + kPad) + 4 * mq) = f32x4{v[r].x, v[r].y, v[r].z, v[r].w};
+            *(lds_f4*)(lds + lofs[r]) = f32x4{v[r].x, v[r].y, v[r].z, v[r].w};
         }
     }
     typedef float4 Side;
@@ -146,9 +190,8 @@ struct Stager<BMN, BK, MC, 4> {
 #pragma unroll
         for (int r = 0; r < NV; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
     }
-    // every staged float4 of a thread has the same mq (kBlock % (BMN/4) == 0): fold r, then across threads via LDS
+    // every staged float4 of a thread has the same mq: fold r, then across threads via LDS
     __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* scratch, lds_f* out, int tid) {
-        static_assert(kBlock % (BMN / 4) == 0, "mq must be fixed per thread");
         constexpr int ROWS = kBlock / (BMN / 4);
         float4 t = s[0];
 #pragma unroll
@@ -167,24 +210,38 @@ struct Stager<BMN, BK, MC, 4> {
 template <int BMN, int BK>
 struct Stager<BMN, BK, MC, 1> {
     static constexpr int NV = BMN * BK / kBlock;
+    static_assert(kBlock % BMN == 0, "m must be fixed per thread");
     float v[NV];
-    bool ok[NV];
-    __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int mn0, int k0, int MN, int K, int tid) {
+    const float* colp;
+    long ld;
+    int krow[NV], lofs[NV];
+    bool colok, ok[NV];
+    int K;
+    __device__ __forceinline__ void init(const float* __restrict__ p, long ld_, int mn0, int MN, int K_, int tid) {
+        K = K_;
+        ld = ld_;
+        const int m = mn0 + tid % BMN;
+        colok = m < MN;
+        colp = p + min(m, MN - 1);
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int k = k0 + f / BMN, m = mn0 + f % BMN;
-            ok[r] = (k < K) && (m < MN);
-            v[r] = p[(long)min(k, K - 1) * ld + min(m, MN - 1)];
+            krow[r] = (tid + kBlock * r) / BMN;
+            lofs[r] = krow[r] * (BMN + kPad) + tid % BMN;
         }
     }
-    __device__ __forceinline__ void store(lds_f* lds, int tid) {
+    __device__ __forceinline__ void load(int k0) {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            int f = tid + kBlock * r;
-            int k = f / BMN, m = f % BMN;
+            const int k = k0 + krow[r];
+            ok[r] = colok && (k < K);
+            v[r] = colp[(long)min(k, K - 1) * ld];
+        }
+    }
+    __device__ __forceinline__ void store(lds_f* lds) {
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
             if (!ok[r]) v[r] = 0.f;
-            lds[k * (BMN + kPad) + m] = v[r];
+            lds[lofs[r]] = v[r];
         }
     }
     typedef float Side;
@@ -193,7 +250,6 @@ struct Stager<BMN, BK, MC, 1> {
         for (int r = 0; r < NV; ++r) s[r] += v[r];
     }
     __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* scratch, lds_f* out, int tid) {
-        static_assert(kBlock % BMN == 0, "m must be fixed per thread");
         constexpr int ROWS = kBlock / BMN;
         float t = s[0];
 #pragma unroll
@@ -212,12 +268,24 @@ struct Stager<BMN, BK, MC, 1> {
 // ---- the tile main loop --------------------------------------------------------------------
 template <int BM, int BN, int BK, int LA, int LB, int VEC>
 struct GemmTile {
-    static constexpr int SA = BM + kPad, SB = BN + kPad;
     static constexpr int WM = BM / 64, WN = BN / 64;
-    static constexpr int kLdsFloats = 2 * BK * (SA + SB);
-    static_assert(BM % 64 == 0 && BN % 64 == 0 && BK % 4 == 0, "tile shape");
+    static constexpr int kImgA = (LA == KC) ? BM * (BK + kPad) : BK * (BM + kPad);  // floats per buffer
+    static constexpr int kImgB = (LB == KC) ? BN * (BK + kPad) : BK * (BN + kPad);
+    static constexpr int kLdsFloats = 2 * (kImgA + kImgB);
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && BK % 8 == 0, "tile shape");
 
-    // acc[wm][wn] (+)= A[m0.., :] . B[n0.., :]^T over k in [0,K).  Rows >= M / cols >= N / k >= K read as 0.
+    // the 4 fragment values (steps s = 0..3) of k-group c for the 32 rows starting at `mn` of an operand image
+    template <int LAYOUT, int BMN>
+    __device__ static __forceinline__ f32x4 frag(const lds_f* img, int mn, int c, int fh) {
+        if constexpr (LAYOUT == KC) {
+            return *(const lds_f4*)(img + mn * (BK + kPad) + 8 * c + 4 * fh);
+        } else {
+            const lds_f* q = img + (8 * c + 4 * fh) * (BMN + kPad) + mn;
+            return f32x4{q[0], q[BMN + kPad], q[2 * (BMN + kPad)], q[3 * (BMN + kPad)]};
+        }
+    }
+
+    // acc[wm][wn] (+)= A[m0.., :] . B[n0.., :]^T over k in [0,K), K >= 1.  Rows >= M / cols >= N / k >= K read as 0.
     // If SIDE_A: side_lds[BM] receives sum_k A[m0+m, k] (valid after the call's final barrier); the operand
     // LDS buffers are reused as scratch for that reduction.
     template <bool SIDE_A>
@@ -230,12 +298,14 @@ struct GemmTile {
         const int lane = tid & 63, wave = tid >> 6;
         const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
         const int fi = lane & 31, fh = lane >> 5;
-        lds_f* const sA0 = lds;                // buffers: A0 | A1 | B0 | B1
-        lds_f* const sB0 = lds + 2 * BK * SA;
+        lds_f* const sA0 = lds;  // buffers: A0 | A1 | B0 | B1
+        lds_f* const sB0 = lds + 2 * kImgA;
 
-        Stager<BM, BK, LA, VEC> ga;
-        Stager<BN, BK, LB, VEC> gb;
         using SG = Stager<BM, BK, LA, VEC>;
+        SG ga;
+        Stager<BN, BK, LB, VEC> gb;
+        ga.init(A, lda, m0, M, K, tid);
+        gb.init(B, ldb, n0, N, K, tid);
         typename SG::Side side[SG::NV];
         if constexpr (SIDE_A) {
 #pragma unroll
@@ -243,42 +313,82 @@ struct GemmTile {
         }
 
         const int nk = (K + BK - 1) / BK;
-        ga.load(A, lda, m0, 0, M, K, tid);
-        gb.load(B, ldb, n0, 0, N, K, tid);
-        ga.store(sA0, tid);  // store() also zeroes out-of-range values, so side_add after it sees masked data
-        gb.store(sB0, tid);
+        // Three-stage pipeline over K tiles: while the MFMAs of tile t run out of LDS buffer t&1, tile t+1 (loaded
+        // from global one whole iteration earlier, so its vmcnt wait is short) is written into buffer (t+1)&1 and
+        // the global loads of tile t+2 are issued.  One barrier per tile: it orders both the reads of buffer t&1
+        // against its refill in iteration t+1 and the writes of buffer (t+1)&1 against their reads.
+        ga.load(0);
+        gb.load(0);
+        ga.store(sA0);  // store() also zeroes out-of-range values, so side_add after it sees masked data
+        gb.store(sB0);
         if constexpr (SIDE_A) ga.side_add(side);
+        if (nk > 1) {
+            ga.load(BK);
+            gb.load(BK);
+        }
         __syncthreads();
 
-        for (int kt = 0; kt < nk; ++kt) {
+        // The steady-state body is branch-free (the last two tiles are peeled) so that it is ONE scheduling region:
+        // a wave issues in order, so the staging stores, the next global loads and their address arithmetic should
+        // sit BETWEEN the MFMAs (64 cycles of pipe time each) rather than before/after a solid MFMA block.
+        auto body = [&](int kt, auto store_next, auto load_next2) {
             const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            if (more) {  // issue next tile's global loads before this tile's MFMAs (latency hides under them)
-                ga.load(A, lda, m0, (kt + 1) * BK, M, K, tid);
-                gb.load(B, ldb, n0, (kt + 1) * BK, N, K, tid);
+            const lds_f* imgA = sA0 + cur * kImgA;
+            const lds_f* imgB = sB0 + cur * kImgB;
+            f32x4 a[BK / 8][WM], b[BK / 8][WN];
+#pragma unroll
+            for (int c = 0; c < BK / 8; ++c) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[c][i] = frag<LA, BM>(imgA, wm0 + i * 32 + fi, c, fh);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[c][j] = frag<LB, BN>(imgB, wn0 + j * 32 + fi, c, fh);
             }
-            const lds_f* a_base = sA0 + cur * (BK * SA) + fh * SA + wm0 + fi;
-            const lds_f* b_base = sB0 + cur * (BK * SB) + fh * SB + wn0 + fi;
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float a[WM], b[WN];
-#pragma unroll
-                for (int i = 0; i < WM; ++i) a[i] = a_base[kk * SA + i * 32];
-#pragma unroll
-                for (int j = 0; j < WN; ++j) b[j] = b_base[kk * SB + j * 32];
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            if (more) {
-                ga.store(sA0 + (cur ^ 1) * (BK * SA), tid);
-                gb.store(sB0 + (cur ^ 1) * (BK * SB), tid);
+#ifndef VGAN_ABLATE_NO_LDS_STORE
+            if constexpr (decltype(store_next)::value) {
+                ga.store(sA0 + (cur ^ 1) * kImgA);
+                gb.store(sB0 + (cur ^ 1) * kImgB);
                 if constexpr (SIDE_A) ga.side_add(side);
             }
+#endif
+#ifndef VGAN_ABLATE_NO_GLOBAL
+            if constexpr (decltype(load_next2)::value) {
+                ga.load((kt + 2) * BK);
+                gb.load((kt + 2) * BK);
+            }
+#endif
+#pragma unroll
+            for (int c = 0; c < BK / 8; ++c)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+#ifndef VGAN_ABLATE_NO_MFMA
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i][st], b[c][j][st], acc[i][j], 0, 0, 0);
+#else
+                            acc[i][j][st] += a[c][i][st] * b[c][j][st];
+#endif
+#if !defined(VGAN_SCHED_NONE)
+            // let the scheduler interleave the LDS traffic with the MFMA chain inside this single-block body
+            // (measured on MI355X, 64x64x32 tiles: none 74.6 / hand-written group barriers 79.6 / iglp_opt(0) 87.5 TFLOP/s
+            // at one wave per SIMD)
+            __builtin_amdgcn_iglp_opt(0);
+#endif
+#ifndef VGAN_ABLATE_NO_BARRIER
             __syncthreads();
+#endif
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) body(kt, T{}, T{});
+        if (kt + 1 < nk) {
+            body(kt, T{}, F{});
+            ++kt;
         }
+        body(kt, F{}, F{});
+
         if constexpr (SIDE_A) {
             SG::side_reduce(side, lds, side_lds, tid);
             __syncthreads();

@@ -5,7 +5,7 @@
 
 namespace vgan {
 
-constexpr int LBM = 64, LBN = 64, LBK = 16;
+constexpr int LBM = 64, LBN = 64, LBK = 32;
 
 // y = x . W^T + b           A = x (KC), B = W (KC)
 template <int VEC>

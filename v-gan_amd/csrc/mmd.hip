@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <array>
@@ -102,8 +103,9 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __rest
         float4 o;
         o.x = (red[0] + red[1]) + (red[2] + red[3]);
         o.y = (red[4] + red[5]) + (red[6] + red[7]);
-        o.z = 0.f;
-        o.w = 0.f;
+        // placement census (diagnostic only; never read by the product): HW_ID and XCC_ID of the wave that closed the tile
+        o.z = __uint_as_float(__builtin_amdgcn_s_getreg((31 << 11) | 4));
+        o.w = __uint_as_float(__builtin_amdgcn_s_getreg((31 << 11) | 20));
         reinterpret_cast<float4*>(partial)[blockIdx.x] = o;
     }
 }
@@ -318,6 +320,7 @@ extern "C" int vgan_mmd_gram(const float* Z, int ldz, const float* sq, int n, in
     const TileDesc* td = reinterpret_cast<const TileDesc*>(tiles);
     const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
     dim3 grid(ntiles), block(kBlock);
+    static const int dyn_lds = getenv("VGAN_GRAM_DYNLDS") ? atoi(getenv("VGAN_GRAM_DYNLDS")) : 0;  // occupancy experiment knob
     if (calibrate) {
         if (vec)
             hipLaunchKernelGGL((mmd_gram_kernel<4, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
@@ -325,7 +328,7 @@ extern "C" int vgan_mmd_gram(const float* Z, int ldz, const float* sq, int n, in
             hipLaunchKernelGGL((mmd_gram_kernel<1, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
     } else {
         if (vec)
-            hipLaunchKernelGGL((mmd_gram_kernel<4, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
+            hipLaunchKernelGGL((mmd_gram_kernel<4, false>), grid, block, dyn_lds, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
         else
             hipLaunchKernelGGL((mmd_gram_kernel<1, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
     }
