@@ -1,0 +1,207 @@
+"""TEST INFRASTRUCTURE ONLY: a kernel provider with HipOps' method set over CPU tensors, built on the
+numpy oracle.  It lets the host logic of the product (step engine, fit loop, row-sharded data parallel
+exchange over gloo) run in the CPU-only test tier.  The product never imports this file.
+"""
+import numpy as np
+import torch
+
+from oracle import vgan_oracle as orc
+from vgan_amd import lib as _lib
+
+TF_SLOT, TF_TWICE, TF_STORE, TF_MIRROR, TF_NEG = 3, 4, 8, 16, 32
+
+
+def _np(t):
+    return t.numpy() if t is not None else None
+
+
+def pack_key(u, row):
+    return (np.asarray(u, dtype=np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.uint64(0xFFFFFFFF - row)
+
+
+class CpuOps:
+    name = "cpu-oracle (tests only)"
+
+    def __init__(self):
+        self.lib = _lib.load()  # host-side helpers of the .so (tile tables) work without a GPU
+
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None):
+        flat, cnt = _lib.build_tiles(n, grad_mode, rank, world)
+        return torch.tensor(flat, dtype=torch.int32).view(cnt, 8)
+
+    def colmax_chunks(self, n):
+        return self.lib.vgan_colmax_chunks(n)
+
+    # ---- Linear
+    def linear_forward(self, x, W, b, y):
+        y.copy_(torch.as_tensor(_np(x).astype(np.float64) @ _np(W).astype(np.float64).T + (_np(b) if b is not None else 0)))
+
+    def linear_backward_input(self, dy, W, dx):
+        dx.copy_(torch.as_tensor(_np(dy).astype(np.float64) @ _np(W).astype(np.float64)))
+
+    def linear_backward_params(self, dy, x, dW, db, splits=1, slab_stride=0):
+        n = dy.shape[0]
+        if splits == 1:
+            dW.copy_(torch.as_tensor(_np(dy).astype(np.float64).T @ _np(x).astype(np.float64)))
+            if db is not None:
+                db.copy_(torch.as_tensor(_np(dy).astype(np.float64).sum(0)))
+            return
+        # slabs: dW/db are views into slab 0 of a [splits, slab_stride] buffer
+        kchunk = ((n + splits - 1) // splits + 3) // 4 * 4
+        for s in range(splits):
+            lo, hi = min(s * kchunk, n), min((s + 1) * kchunk, n)
+            part_w = _np(dy)[lo:hi].astype(np.float64).T @ _np(x)[lo:hi].astype(np.float64)
+            wv = torch.as_strided(dW, dW.shape, dW.stride(), dW.storage_offset() + s * slab_stride)
+            wv.copy_(torch.as_tensor(part_w))
+            if db is not None:
+                bv = torch.as_strided(db, db.shape, db.stride(), db.storage_offset() + s * slab_stride)
+                bv.copy_(torch.as_tensor(_np(dy)[lo:hi].astype(np.float64).sum(0)))
+
+    def reduce_slabs(self, src, slab_stride, nslabs, dst):
+        flat = src.reshape(-1)
+        acc = torch.zeros_like(dst)
+        for s in range(nslabs):
+            acc += flat[s * slab_stride:s * slab_stride + dst.numel()]
+        dst.copy_(acc)
+
+    # ---- mask / projection
+    @staticmethod
+    def _rows(rows, row_cursor, row_batches, row_stride, row_offset, n):
+        if rows is None:
+            return np.arange(row_offset, row_offset + n)
+        b = int(row_cursor.item()) % row_batches if row_cursor is not None else 0
+        flat = rows.reshape(-1).numpy()
+        return flat[b * row_stride + row_offset: b * row_stride + row_offset + n].astype(np.int64)
+
+    def mask_project_forward(self, logits, data, rows, S, U, Zx, Zy, sqx, sqy, row_cursor=None, row_batches=1, row_stride=0,
+                             row_offset=0):
+        n, d = logits.shape
+        u, s = orc.upper_softmax_forward(_np(logits).astype(np.float32))
+        S.copy_(torch.as_tensor(s))
+        if U is not None:
+            U.copy_(torch.as_tensor(u))
+        X = _np(data)[self._rows(rows, row_cursor, row_batches, row_stride, row_offset, n)]
+        Y = u * X
+        if Zx is not None:
+            Zx[:, :d].copy_(torch.as_tensor(X))
+        Zy[:, :d].copy_(torch.as_tensor(Y))
+        if sqx is not None:
+            sqx.copy_(torch.as_tensor((X.astype(np.float64) ** 2).sum(1)))
+        sqy.copy_(torch.as_tensor((Y.astype(np.float64) ** 2).sum(1)))
+
+    def gather_rows(self, data, rows, out, sq, row_cursor=None, row_batches=1, row_stride=0, row_offset=0):
+        n, d = out.shape[0], data.shape[1]
+        X = _np(data)[self._rows(rows, row_cursor, row_batches, row_stride, row_offset, n)]
+        out[:, :d].copy_(torch.as_tensor(X))
+        if sq is not None:
+            sq.copy_(torch.as_tensor((X.astype(np.float64) ** 2).sum(1)))
+
+    def upper_softmax_forward(self, logits, S, U):
+        u, s = orc.upper_softmax_forward(_np(logits).astype(np.float32))
+        S.copy_(torch.as_tensor(s))
+        if U is not None:
+            U.copy_(torch.as_tensor(u))
+
+    def mask_from_softmax(self, S, U):
+        s = _np(S)
+        U.copy_(torch.as_tensor(np.where(s < np.float32(1.0 / s.shape[1]), s, np.float32(1.0))))
+
+    def colmax(self, S, row_offset, part, colkey, from_softmax=True):
+        s = _np(S).astype(np.float32)
+        n, d = s.shape
+        u = np.where(s < np.float32(1.0 / d), s, np.float32(1.0)) if from_softmax else s
+        keys = pack_key(u, (row_offset + np.arange(n, dtype=np.uint64))[:, None])
+        colkey.copy_(torch.as_tensor(keys.max(axis=0).view(np.int64)))
+
+    def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits):
+        s = _np(S).astype(np.float32)
+        n, d = s.shape
+        g = _np(gU)[:, :d].astype(np.float32).copy()
+        if colkey is not None:
+            rows = 0xFFFFFFFF - (_np(colkey).view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.int64) - row_offset
+            for j in range(d):
+                if 0 <= rows[j] < n:
+                    g[rows[j], j] += np.float32(-pen_weight / d)
+        dlogits.copy_(torch.as_tensor(orc.upper_softmax_backward(g, s)))
+
+    # ---- MMD (tile-table driven, like the kernel)
+    def row_sqnorm(self, Z, sq, p):
+        sq.copy_(torch.as_tensor((_np(Z)[:, :p].astype(np.float64) ** 2).sum(1)))
+
+    def mmd_gram(self, Z, sq, n, p, bw, tiles, calibrate, Wg, wrow0, partial):
+        z = _np(Z)[:, :p].astype(np.float64)
+        s = _np(sq).astype(np.float64)
+        T = 64
+        bwv = float(bw.reshape(-1)[0]) if not calibrate else None
+        part = np.zeros((tiles.shape[0], 4), dtype=np.float32)
+        for t, (r0, c0, rlim, clim, fl, *_rest) in enumerate(tiles.tolist()):
+            ri, cj = np.arange(r0, min(r0 + T, rlim)), np.arange(c0, min(c0 + T, clim))
+            L = np.maximum(s[ri][:, None] + s[cj][None, :] - 2 * z[ri] @ z[cj].T, 0.0)
+            if calibrate:
+                part[t, 1] = L.sum()
+                continue
+            K = np.zeros_like(L)
+            dK = np.zeros_like(L)
+            for sc in orc.rbf_scales(bwv, np.float64):
+                e = np.exp(-L / sc)
+                K += e
+                dK -= e / sc
+            part[t, 0] = K.sum()
+            if (fl & TF_STORE) and Wg is not None:
+                sgn = -1.0 if fl & TF_NEG else 1.0
+                w = sgn * 2.0 / (n * n) * dK
+                wg = _np(Wg)
+                wg[np.ix_(ri - wrow0, cj)] = w
+                if fl & TF_MIRROR:
+                    wg[np.ix_(cj - wrow0, ri)] = w.T
+        partial.reshape(-1, 4)[:tiles.shape[0]].copy_(torch.as_tensor(part))
+
+    def mmd_reduce(self, partial, tiles, stats, zero_first=True):
+        st = np.zeros(4)
+        p = _np(partial).reshape(-1, 4).astype(np.float64)
+        for t, row in enumerate(tiles.tolist()):
+            fl = row[4]
+            w = 2.0 if fl & TF_TWICE else 1.0
+            st[fl & TF_SLOT] += w * p[t, 0]
+            st[3] += (2.0 if (fl & TF_SLOT) == 1 else w) * p[t, 1]
+        if zero_first:
+            stats.copy_(torch.as_tensor(st))
+        else:
+            stats.add_(torch.as_tensor(st))
+
+    def mmd_set_bandwidth(self, stats, n, bw):
+        N = 2.0 * n
+        bw.fill_(float(stats[3]) / (N * N - N))
+
+    def mmd_loss(self, stats, colkey, n, d, weight, loss, loss_accum=None, accum_scale=1.0, step_counter=None):
+        st = _np(stats)
+        v = (st[0] - 2 * st[1] + st[2]) / (float(n) * n)
+        if colkey is not None:
+            vals = (_np(colkey).view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32)
+            v += weight * float(np.mean(1.0 - vals.astype(np.float64)))
+        loss.fill_(v)
+        if loss_accum is not None:
+            loss_accum += v * accum_scale
+        if step_counter is not None:
+            step_counter += 1
+
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out):
+        w = _np(Wg)[:nr, :ncols].astype(np.float64)
+        z = _np(Z)[:ncols, :p].astype(np.float64)
+        r = 2.0 * (w.sum(1, keepdims=True) * z[wrow0:wrow0 + nr] - w @ z)
+        if mul is not None:
+            r = r * _np(mul)[:nr, :p]
+        out[:nr, :p].copy_(torch.as_tensor(r))
+
+    # ---- optimiser / noise
+    def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+        pn, sn, an = orc.adadelta_step(_np(p).astype(np.float64), _np(g).astype(np.float64) * grad_scale, _np(sq).astype(np.float64),
+                                       _np(acc).astype(np.float64), lr, weight_decay, rho, eps)
+        p.copy_(torch.as_tensor(pn))
+        sq.copy_(torch.as_tensor(sn))
+        acc.copy_(torch.as_tensor(an))
+
+    def noise_normal(self, z, seed, step_counter, stream_id=0):
+        g = torch.Generator()
+        g.manual_seed((int(seed) * 1000003 + int(step_counter.item()) * 7919 + int(stream_id)) % (2 ** 63))
+        z.copy_(torch.randn(z.shape, generator=g))

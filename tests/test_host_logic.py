@@ -1,0 +1,109 @@
+"""Host logic of the product on the CPU tier: RNG/shuffle order, flat parameter layout, the step engine and
+the fit loop, run over the test-only CpuOps provider (tests/cpu_ops.py) and checked against the oracle and
+the reference-generated fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from cpu_ops import CpuOps
+from oracle import vgan_oracle as orc
+
+
+def test_epoch_batches_match_dataloader_rng_order():
+    from vgan_amd import vgan as V
+    for N, n in [(1280, 128), (2000, 500), (77, 10)]:
+        torch.manual_seed(5)
+        a = V._epoch_batches_dataloader(N, n)
+        sa = torch.random.get_rng_state()
+        torch.manual_seed(5)
+        b = V.epoch_batches(N, n)
+        sb = torch.random.get_rng_state()
+        assert torch.equal(a, b) and torch.equal(sa, sb)
+        assert b.shape == (N // n, n)
+
+
+def test_synthetic_inputs_identical_to_oracle_copy():
+    from vgan_amd import synth
+    for cfg, rows in [("c1", 300), ("c2", 200), ("c3", 64)]:
+        assert np.array_equal(synth.synthetic_dataset(cfg, rows=rows), orc.synthetic_dataset(cfg, rows=rows))
+    for a, b in zip(synth.synthetic_generator_params(784), orc.synthetic_generator_params(784)):
+        assert np.array_equal(a, b)
+
+
+def make_engine(params, data, n, nb, **kw):
+    from vgan_amd.modules import Generator_big
+    from vgan_amd.trainer import NoKLStepEngine
+    d = data.shape[1]
+    gen = Generator_big(orc.latent_size(d), d)
+    with torch.no_grad():
+        for q, v in zip(gen.parameters(), params):
+            q.copy_(torch.as_tensor(v))
+    return NoKLStepEngine(CpuOps(), gen, torch.as_tensor(data), n, nb, noise="host", loss_accum_scale=1.0, **kw), gen
+
+
+def test_flat_params_layout_and_views():
+    g = load_golden("f2_step_c2.npz")
+    eng, gen = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], 512, 1)
+    fp = eng.fp
+    assert all(o % 4 == 0 for o in fp.offsets) and fp.total % 4 == 0
+    for i, q in enumerate(gen.parameters()):
+        assert q.data.data_ptr() == fp.view(fp.flat, i).data_ptr()  # module parameters ARE the flat buffer
+        assert np.array_equal(q.detach().numpy(), g[f"param0_{i}"])
+    assert list(gen.state_dict()) == [f"main.{k}.{w}" for k in range(4) for w in ("weight", "bias")]
+
+
+@pytest.mark.parametrize("cfg", ["c1", "c2"])
+def test_engine_two_steps_vs_reference_fixture(cfg):
+    g = load_golden(f"f2_step_{cfg}.npz")
+    n = g["batch"].shape[0]
+    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], n, 1)
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    for step in range(2):
+        eng.set_noise(torch.as_tensor(g["noise"]))
+        eng.step()
+        assert abs(float(eng.loss) - float(g[f"loss{step}"])) < 2e-5
+        for i in range(8):
+            ref = g[f"grad{step}_{i}"]
+            np.testing.assert_allclose(eng.fp.view(eng.fp.grad, i).numpy(), ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-8))
+            np.testing.assert_allclose(eng.fp.view(eng.fp.flat, i).numpy(), g[f"param{step + 1}_{i}"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(float(eng.bw), float(g["bw"]), rtol=1e-5)
+
+
+def test_fit_loop_reproduces_reference_run_on_cpu_provider():
+    """The whole VGAN_no_kl.fit host loop (seeding, init order, shuffles, noise draws, epoch means, shared-RBF
+    bandwidth hand-over, sampling) against the reference's own run (fixture f3), kernels emulated by CpuOps."""
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    g = load_golden("f3_traj_c1.npz")
+    model = VGAN_no_kl(batch_size=128, epochs=20, seed=777)
+    model._ops_override = CpuOps()
+    model.device = torch.device("cpu")
+    model.noise_source = "host"
+    model.verbose = False
+    model.fit(g["data"])
+    np.testing.assert_allclose(model.train_history["generator_loss"], g["epoch_losses"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(float(model.bandwidth), float(g["bw"]), rtol=1e-5)
+    assert np.array_equal(model.generate_subspaces(500).numpy(), g["masks"])
+    for i, q in enumerate(model.generator.parameters()):
+        np.testing.assert_allclose(q.detach().numpy(), g[f"paramT_{i}"], rtol=0, atol=5e-5)
+    # reference quirk kept: the process-wide default RBF now carries this run's bandwidth (Mmd_loss_constrained.py:35)
+    assert float(MMDLossConstrained(weight=1).kernel.bandwidth) == pytest.approx(float(g["bw"]), rel=1e-5)
+    model.approx_subspace_dist()
+    assert model.subspaces.shape[1] == 20 and abs(model.proba.sum() - 1) < 1e-12
+    with pytest.raises(NotImplementedError):
+        model.check_if_myopic(g["data"])
+
+
+def test_batch_size_clamp_and_history_shape():
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    X = orc.synthetic_dataset("c1", rows=96)
+    model = VGAN_no_kl(batch_size=500, epochs=3, seed=1)
+    model._ops_override, model.device, model.verbose, model.noise_source = CpuOps(), torch.device("cpu"), False, "host"
+    assert model.fit(X) is None
+    assert model.batch_size == 96 and len(model.train_history["generator_loss"]) == 3
+    assert model.get_params()["generator optimizer"] == "Adadelta"
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None

@@ -1,0 +1,82 @@
+"""Host-built Gram tile tables (vgan_mmd_build_tiles, no GPU needed): every pair of the 2n x 2n matrix is
+covered with the right multiplicity, every needed gradient weight is written exactly once, and the
+XCD-interleaved order is a permutation."""
+import numpy as np
+import pytest
+
+from vgan_amd import lib
+
+T, SLOT, TWICE, STORE, MIRROR, NEG = 64, 3, 4, 8, 16, 32
+
+
+def table(n, mode, rank=0, world=1):
+    flat, cnt = lib.build_tiles(n, mode, rank, world)
+    return np.array(flat, dtype=np.int64).reshape(cnt, 8)
+
+
+def coverage(n, tabs, nrW, wrow0s):
+    """Returns (count matrix [2n,2n] of how often the sums see each pair, writes matrix)."""
+    N = 2 * n
+    seen = np.zeros((N, N))
+    slot_ok = True
+    writes = np.zeros((N, N))
+    for tab, wrow0 in zip(tabs, wrow0s):
+        for r0, c0, rlim, clim, fl, *_ in tab.tolist():
+            ri, cj = np.arange(r0, min(r0 + T, rlim)), np.arange(c0, min(c0 + T, clim))
+            w = 2 if fl & TWICE else 1
+            seen[np.ix_(ri, cj)] += 1
+            if fl & TWICE:
+                seen[np.ix_(cj, ri)] += 1
+            half_r, half_c = r0 >= n, c0 >= n
+            want = 0 if (not half_r and not half_c) else (2 if (half_r and half_c) else 1)
+            slot_ok &= (fl & SLOT) == want and bool(fl & NEG) == (half_r != half_c)
+            assert rlim <= (2 * n if half_r else n) and clim <= (2 * n if half_c else n)
+            if fl & STORE:
+                writes[np.ix_(ri, cj)] += 1
+                if fl & MIRROR:
+                    writes[np.ix_(cj, ri)] += 1
+            del w
+    return seen, writes, slot_ok
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 100, 128, 500, 1024])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_single_rank_tables(n, mode):
+    tab = table(n, mode)
+    assert len({tuple(r[:2]) for r in tab.tolist()}) == len(tab), "duplicate tile after XCD interleave"
+    seen, writes, slot_ok = coverage(n, [tab], None, [n if mode == 1 else 0])
+    assert slot_ok
+    N = 2 * n
+    want = np.ones((N, N))
+    want[:n, n:] = 0  # the XY block is evaluated once, as (Y rows) x (X cols)
+    assert np.array_equal(seen, want)
+    if mode == 0:
+        assert writes.sum() == 0
+    elif mode == 1:
+        assert np.array_equal(writes[n:], np.ones((n, N))) and writes[:n].sum() == 0
+    else:
+        assert np.array_equal(writes, np.ones((N, N)))
+
+
+@pytest.mark.parametrize("n,world", [(128, 2), (512, 8), (1024, 4), (96, 3)])
+def test_row_sharded_tables(n, world):
+    tabs = [table(n, 1, r, world) for r in range(world)]
+    seen, writes, slot_ok = coverage(n, tabs, None, [0] * world)
+    assert slot_ok
+    N = 2 * n
+    want = np.ones((N, N))
+    want[:n, n:] = 0
+    assert np.array_equal(seen, want)          # union of the ranks = the whole matrix, no symmetry needed
+    assert np.array_equal(writes[n:], np.ones((n, N))) and writes[:n].sum() == 0
+    for r, tab in enumerate(tabs):             # each rank only touches its own rows
+        lo, hi = n * r // world, n * (r + 1) // world
+        rows = tab[:, 0] % n
+        assert ((rows >= lo) & (rows < hi)).all()
+
+
+def test_bad_arguments():
+    l = lib.load()
+    assert l.vgan_mmd_build_tiles(0, 1, 0, 1, None, 0) == -1
+    assert l.vgan_mmd_build_tiles(64, 3, 0, 1, None, 0) == -1
+    assert l.vgan_mmd_build_tiles(64, 2, 0, 2, None, 0) == -1
+    assert b"grad_mode 2" in l.vgan_last_error()

@@ -119,14 +119,29 @@ class _RunFolder:
         self.generator_optimizer = f"Loaded Model from {path_to_generator} with {ndims} dimensions in the latent space"
         self._latent_size = max(int(ndims / 16), 1)
 
+    def _ops(self):
+        return getattr(self, "_ops_override", None) or default_ops()
+
+    def _generator_forward(self, z):
+        """Generator_big forward (4 Linear + upper_softmax) straight on the kernel provider, no autograd."""
+        ops = self._ops()
+        h = z.to(device=self.device, dtype=torch.float32).contiguous()
+        for m in self.generator.main:
+            if isinstance(m, torch.nn.Linear):
+                y = torch.empty(h.shape[0], m.out_features, dtype=torch.float32, device=h.device)
+                ops.linear_forward(h, m.weight.detach(), m.bias.detach(), y)
+                h = y
+        S, U = torch.empty_like(h), torch.empty_like(h)
+        ops.upper_softmax_forward(h, S, U)
+        return U
+
     def generate_subspaces(self, nsubs):
         """src/vgan.py:355-370 / 639-647: seeded CPU noise -> generator -> bool mask ``u >= 1/d``."""
         noise_tensor = torch.Tensor(nsubs, self._latent_size).to("cpu")
         if self.seed is not None:
             torch.manual_seed(self.seed)
         noise_tensor.normal_()
-        with torch.no_grad():
-            u = self.generator(noise_tensor.to(self.device))
+        u = self._generator_forward(noise_tensor)
         return torch.greater_equal(u, 1 / u.shape[1])
 
     def sample(self, nsubs):
@@ -136,7 +151,7 @@ class _RunFolder:
     def approx_subspace_dist(self, subspace_count=500, add_leftover_features=False):
         """src/vgan.py:372-382 / 649-659."""
         u = self.generate_subspaces(subspace_count)
-        unique_subspaces, proba = np.unique(np.array(u.to("cpu")), axis=0, return_counts=True)
+        unique_subspaces, proba = np.unique(u.to("cpu").numpy(), axis=0, return_counts=True)
         if (unique_subspaces.sum(axis=0) < 1).sum() != 0 and add_leftover_features:
             unique_subspaces = np.append(unique_subspaces, [unique_subspaces.sum(axis=0) < 1], axis=0)
             proba = np.append(proba / proba.sum(), 1)
@@ -198,9 +213,6 @@ class VGAN_no_kl(_RunFolder):
         if shared is not None:
             eng.set_bandwidth(float(shared))
         return eng
-
-    def _ops(self):
-        return getattr(self, "_ops_override", None) or default_ops()
 
     def fit(self, X):
         """src/vgan.py:546-637.  X: [Ntrain, d] array-like.  Returns None; sets generator, bandwidth,
