@@ -96,12 +96,25 @@ def kernel_rooflines(eng):
     }
 
 
+def usable_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU boxes expose
+    256 logical CPUs but grant a 16-CPU quota; oversubscribing them makes the baseline ~10x slower than it is)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(data, params, seconds):
     """The reference's CPU path cannot travel to this box; its op-for-op PyTorch port (oracle/torch_port.py,
     pinned to the reference by tests/test_oracle_golden.py) is timed instead on a bounded sample."""
     from oracle import torch_port as port
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     tr = port.PortNoKL(params)
     rng = np.random.default_rng(0)
     L = params[0].shape[1]

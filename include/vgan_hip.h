@@ -79,9 +79,11 @@ int vgan_gather_rows(const float* data, int ldd, const int32_t* rows, const uint
 /* dlogits = softmax-Jacobian( [S < 1/d] * (gU + penalty_grad) ), the autograd of Generator.py:19-21.
  * colkey (may be NULL): packed column arg-max keys from vgan_colmax; row r of column j gets
  * -pen_weight/d added when it holds column j's maximum (topk(U,1,0), Mmd_loss_constrained.py:50). */
-int vgan_mask_backward(const float* gU, int ldg, const float* S, int lds, const uint64_t* colkey,
-                       float pen_weight, int row_offset, float* dlogits, int ldo, int n, int d,
-                       vgan_stream_t stream);
+/* gU may be given as `nslabs` partial slabs `slab_stride` elements apart (split-K output of
+ * vgan_mmd_backward); they are summed in ascending order inside the kernel. */
+int vgan_mask_backward(const float* gU, int ldg, int nslabs, int64_t slab_stride, const float* S,
+                       int lds, const uint64_t* colkey, float pen_weight, int row_offset,
+                       float* dlogits, int ldo, int n, int d, vgan_stream_t stream);
 /* colkey[j] = max over rows of pack(U[i,j], row_offset + i)  (value in the high 32 bits, ~row in
  * the low 32 bits; lowest row wins ties).  from_softmax != 0: the input is S and U is derived from
  * it; otherwise the input is U itself (must be > 0).  part: workspace [chunks*d] u64 with
@@ -89,6 +91,9 @@ int vgan_mask_backward(const float* gU, int ldg, const float* S, int lds, const 
 int vgan_colmax_chunks(int n);
 int vgan_colmax(const float* S, int lds, int from_softmax, int row_offset, uint64_t* part,
                 uint64_t* colkey, int n, int d, vgan_stream_t stream);
+/* first half of vgan_colmax only: per-chunk keys into part[chunks*d] (finished by vgan_mmd_finalize) */
+int vgan_colmax_partial(const float* S, int lds, int from_softmax, int row_offset, uint64_t* part,
+                        int n, int d, vgan_stream_t stream);
 /* dense U from S (for callers that need the mask tensor itself) */
 int vgan_mask_from_softmax(const float* S, int lds, float* U, int ldu, int n, int d, vgan_stream_t stream);
 /* plain row softmax -> upper_softmax for a dense generator output (no projection) */
@@ -139,23 +144,34 @@ int vgan_mmd_set_bandwidth(const double* stats, int n, float* bw, vgan_stream_t 
 int vgan_mmd_loss(const double* stats, const uint64_t* colkey, int n, int d, float weight,
                   float* loss, float* loss_accum, float accum_scale, uint64_t* step_counter,
                   vgan_stream_t stream);
+/* Single-rank step tail in one launch = vgan_mmd_reduce (zero_first) + the second half of vgan_colmax
+ * + vgan_mmd_loss: partial[] -> stats[4]; colpart[chunks*d] -> colkey[d] (colpart may be NULL: no
+ * penalty term); loss / loss_accum / step_counter as in vgan_mmd_loss. */
+int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int ntiles, const uint64_t* colpart,
+                      int chunks, uint64_t* colkey, int n, int d, float weight, double* stats,
+                      float* loss, float* loss_accum, float accum_scale, uint64_t* step_counter,
+                      vgan_stream_t stream);
 /* dZ[i - wrow0, :] = 2 (rowsum(Wg_i) z_i - Wg_i . Z) for the nr rows starting at wrow0;
  * if mul != NULL the result is multiplied elementwise by mul[i - wrow0, :] (the `U * batch`
- * product rule: gU = dY * X).  Z is [ncols, p], Wg is [nr, ncols]. */
+ * product rule: gU = dY * X).  Z is [ncols, p], Wg is [nr, ncols].
+ * splits > 1: the contraction over the Z rows is cut into `splits` slices and slice s writes its
+ * PARTIAL result to out + s*slab_stride (the result is linear in the slice sums); the consumer adds
+ * the slabs (vgan_mask_backward does, or vgan_reduce_slabs). */
 int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr,
                       int ncols, int p, const float* mul, int ldmul, float* out, int ldo,
-                      vgan_stream_t stream);
+                      int splits, int64_t slab_stride, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch.optim.Adadelta over one flat parameter buffer  (src/vgan.py:567-568, :619)
  *   g += wd*p; v = rho v + (1-rho) g^2; delta = sqrt(a+eps)/sqrt(v+eps) g; a = rho a + (1-rho) delta^2;
- *   p -= lr*delta.   grad_scale multiplies g first (1 for plain training).
+ *   p -= lr*delta.   grad_scale multiplies g first (1 for plain training).  g may be `nslabs` split-K
+ *   slabs `slab_stride` elements apart (see vgan_linear_backward_params): summed in ascending order.
  * ------------------------------------------------------------------------------------------- */
-int vgan_adadelta_step(float* p, const float* g, float* sq_avg, float* acc_delta, int64_t count,
-                       float lr, float rho, float eps, float weight_decay, float grad_scale,
-                       vgan_stream_t stream);
+int vgan_adadelta_step(float* p, const float* g, int nslabs, int64_t slab_stride, float* sq_avg,
+                       float* acc_delta, int64_t count, float lr, float rho, float eps,
+                       float weight_decay, float grad_scale, vgan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Noise feed  (src/vgan.py:610 `noise_tensor.normal_()`): standard normals from a counter-based

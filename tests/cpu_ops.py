@@ -106,17 +106,32 @@ class CpuOps:
         s = _np(S)
         U.copy_(torch.as_tensor(np.where(s < np.float32(1.0 / s.shape[1]), s, np.float32(1.0))))
 
-    def colmax(self, S, row_offset, part, colkey, from_softmax=True):
+    def colmax(self, S, row_offset, part, colkey, from_softmax=True):  # `part` unused by the CPU stand-in
         s = _np(S).astype(np.float32)
         n, d = s.shape
         u = np.where(s < np.float32(1.0 / d), s, np.float32(1.0)) if from_softmax else s
         keys = pack_key(u, (row_offset + np.arange(n, dtype=np.uint64))[:, None])
         colkey.copy_(torch.as_tensor(keys.max(axis=0).view(np.int64)))
 
-    def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits):
+    def colmax_partial(self, S, row_offset, part, from_softmax=True):
+        # the CPU stand-in keeps the finished keys in chunk 0 and zeros elsewhere (max-reduction neutral)
+        n, d = S.shape
+        part.zero_()
+        self.colmax(S, row_offset, None, part[:d], from_softmax)
+
+    def mmd_finalize(self, partial, tiles, colpart, chunks, colkey, n, d, weight, stats, loss, loss_accum=None, accum_scale=1.0,
+                     step_counter=None):
+        self.mmd_reduce(partial, tiles, stats, True)
+        if colpart is not None:
+            colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
+        self.mmd_loss(stats, colkey if colpart is not None else None, n, d, weight, loss, loss_accum, accum_scale, step_counter)
+
+    def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits, nslabs=1, slab_stride=0):
         s = _np(S).astype(np.float32)
         n, d = s.shape
         g = _np(gU)[:, :d].astype(np.float32).copy()
+        for q in range(1, nslabs):
+            g += torch.as_strided(gU, gU.shape, gU.stride(), gU.storage_offset() + q * slab_stride).numpy()[:, :d]
         if colkey is not None:
             rows = 0xFFFFFFFF - (_np(colkey).view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.int64) - row_offset
             for j in range(d):
@@ -185,16 +200,22 @@ class CpuOps:
         if step_counter is not None:
             step_counter += 1
 
-    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out):
-        w = _np(Wg)[:nr, :ncols].astype(np.float64)
-        z = _np(Z)[:ncols, :p].astype(np.float64)
-        r = 2.0 * (w.sum(1, keepdims=True) * z[wrow0:wrow0 + nr] - w @ z)
-        if mul is not None:
-            r = r * _np(mul)[:nr, :p]
-        out[:nr, :p].copy_(torch.as_tensor(r))
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0):
+        kchunk = ((ncols + splits - 1) // splits + 31) // 32 * 32
+        for sl in range(splits):
+            lo, hi = min(sl * kchunk, ncols), min((sl + 1) * kchunk, ncols)
+            w = _np(Wg)[:nr, lo:hi].astype(np.float64)
+            z = _np(Z)[:ncols, :p].astype(np.float64)
+            r = 2.0 * (w.sum(1, keepdims=True) * z[wrow0:wrow0 + nr] - w @ z[lo:hi])
+            if mul is not None:
+                r = r * _np(mul)[:nr, :p]
+            o = torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + sl * slab_stride)
+            o[:nr, :p].copy_(torch.as_tensor(r))
 
     # ---- optimiser / noise
-    def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+    def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
+        if nslabs > 1:
+            g = sum(torch.as_strided(g, g.shape, g.stride(), g.storage_offset() + q * slab_stride) for q in range(nslabs))
         pn, sn, an = orc.adadelta_step(_np(p).astype(np.float64), _np(g).astype(np.float64) * grad_scale, _np(sq).astype(np.float64),
                                        _np(acc).astype(np.float64), lr, weight_decay, rho, eps)
         p.copy_(torch.as_tensor(pn))

@@ -130,6 +130,10 @@ def run_mmd(ops, X, Y, U, weight, bw=None, grad_mode=1):
         dZ = torch.empty(nr, pp, device="cuda")
         ops.mmd_backward(Wg, Z, wrow0, nr, 2 * n, pp, None, dZ)
         assert not torch.isnan(Wg).any(), "tile table left part of Wg unwritten"
+        # split-K slabs of the same product must sum to it
+        slabs = torch.full((3, nr, pp), float("nan"), device="cuda")
+        ops.mmd_backward(Wg, Z, wrow0, nr, 2 * n, pp, None, slabs[0], 3, nr * pp)
+        np.testing.assert_allclose(host(slabs.sum(0)), host(dZ), rtol=0, atol=1e-5 * float(dZ.abs().max()) + 1e-9)
         dZ = host(dZ)[:, :p]
     return dict(loss=float(loss), bw=float(bwt), stats=host(stats), dZ=dZ, colkey=host(colkey))
 
@@ -238,7 +242,7 @@ def test_full_step_golden(ops, cfg):
         assert abs(float(eng.loss) - float(g[f"loss{step}"])) < 2e-5
         for i in range(8):
             ref = g[f"grad{step}_{i}"]
-            got = host(eng.fp.view(eng.fp.grad, i))
+            got = host(eng.grad_view(i))
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-8))
             np.testing.assert_allclose(host(eng.fp.view(eng.fp.flat, i)), g[f"param{step + 1}_{i}"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(float(eng.bw), float(g["bw"]), rtol=1e-5)
@@ -294,9 +298,9 @@ def test_c3_step_vs_fp64_reference(ops):
     ops.mask_from_softmax(eng.S, U)
     assert int((host(U) >= np.float32(1 / d)).sum()) == int(g["nsel_f64"])
     for i in range(8):
-        gn = np.sqrt((host(eng.fp.view(eng.fp.grad, i)).astype(np.float64) ** 2).sum())
+        gn = np.sqrt((host(eng.grad_view(i)).astype(np.float64) ** 2).sum())
         np.testing.assert_allclose(gn, float(g[f"gnorm_f64_{i}"]), rtol=5e-3)
-    np.testing.assert_allclose(host(eng.fp.view(eng.fp.grad, 6))[:8, :16], g["g6slice_f64"], rtol=0,
+    np.testing.assert_allclose(host(eng.grad_view(6))[:8, :16], g["g6slice_f64"], rtol=0,
                                atol=5e-3 * np.abs(g["g6slice_f64"]).max())
 
 

@@ -65,7 +65,7 @@ def test_engine_two_steps_vs_reference_fixture(cfg):
         assert abs(float(eng.loss) - float(g[f"loss{step}"])) < 2e-5
         for i in range(8):
             ref = g[f"grad{step}_{i}"]
-            np.testing.assert_allclose(eng.fp.view(eng.fp.grad, i).numpy(), ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-8))
+            np.testing.assert_allclose(eng.grad_view(i).numpy(), ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-8))
             np.testing.assert_allclose(eng.fp.view(eng.fp.flat, i).numpy(), g[f"param{step + 1}_{i}"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(float(eng.bw), float(g["bw"]), rtol=1e-5)
 

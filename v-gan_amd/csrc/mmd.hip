@@ -162,13 +162,62 @@ __global__ void mmd_loss_kernel(const double* __restrict__ stats, const unsigned
     }
 }
 
+// ---- single-GPU step tail in ONE launch: per-tile partials -> block statistics, column chunk keys -> arg-max keys,
+// then the loss (replaces mmd_reduce + colmax_final + mmd_loss, three latency-bound launches).
+__global__ __launch_bounds__(1024) void mmd_finalize_kernel(const float* __restrict__ partial, const TileDesc* __restrict__ tiles,
+                                                           int ntiles, const unsigned long long* __restrict__ colpart, int chunks,
+                                                           unsigned long long* __restrict__ colkey, int n, int d, float weight,
+                                                           double* __restrict__ stats, float* __restrict__ loss,
+                                                           float* __restrict__ loss_accum, float accum_scale,
+                                                           unsigned long long* __restrict__ step_counter) {
+    __shared__ double red[16][5];
+    double s[5] = {0, 0, 0, 0, 0};  // Sxx, Sxy, Syy, sumL, penalty
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        const int fl = tiles[t].flags;
+        const double w = (fl & VGAN_TF_TWICE) ? 2.0 : 1.0;
+        const float4 pv = reinterpret_cast<const float4*>(partial)[t];
+        s[fl & VGAN_TF_SLOT_MASK] += w * (double)pv.x;
+        s[3] += (((fl & VGAN_TF_SLOT_MASK) == 1) ? 2.0 : w) * (double)pv.y;
+    }
+    if (colpart != nullptr) {
+        for (int j = threadIdx.x; j < d; j += blockDim.x) {
+            unsigned long long b = 0ull;
+            for (int c = 0; c < chunks; ++c) {
+                const unsigned long long k = colpart[(long)c * d + j];
+                b = k > b ? k : b;
+            }
+            colkey[j] = b;
+            s[4] += 1.0 - (double)colkey_value(b);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        s[q] = wave_sum(s[q]);
+        if (lane == 0) red[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[5] = {0, 0, 0, 0, 0};
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w)
+            for (int q = 0; q < 5; ++q) t[q] += red[w][q];
+        for (int q = 0; q < 4; ++q) stats[q] = t[q];
+        const double nn = (double)n * (double)n;
+        const double v = (t[0] - 2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
+        loss[0] = (float)v;
+        if (loss_accum) loss_accum[0] += (float)(v * (double)accum_scale);
+        if (step_counter) step_counter[0] += 1ull;
+    }
+}
+
 // ---- backward: dZ_i = 2 (rowsum(Wg_i) z_i - (Wg . Z)_i), optionally times mul ---------------
 // A = Wg [nr, ncols] (KC), B(j = feature, k = Z row) = Z[k*ldz + j] (MC).
 template <int VEC>
 __global__ __launch_bounds__(kBlock, 2) void mmd_backward_kernel(const float* __restrict__ Wg, int ldw, const float* __restrict__ Z,
                                                                 int ldz, int wrow0, int nr, int ncols, int p,
                                                                 const float* __restrict__ mul, int ldmul, float* __restrict__ out,
-                                                                int ldo) {
+                                                                int ldo, int kchunk, long slab_stride) {
     using G = GemmTile<GT, GT, GBK, KC, MC, VEC>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float rs[GT];
@@ -183,9 +232,20 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_backward_kernel(const float* __
     const int rows_in_band = min(4, gy - band * 4);
     const int by = band * 4 + rem % rows_in_band, bx = rem / rows_in_band;
     const int m0 = by * GT, n0 = bx * GT;
+    // split-K over the Z rows (blockIdx.y): slice s contributes 2 (rowsum_s(Wg) z - (Wg_s . Z_s)) -- the result is
+    // linear in the slice sums -- to slab s of `out`; the consumer (mask backward) adds the slabs.  With one
+    // workgroup per CU the K = 2n loop runs at one wave per SIMD; slices raise that to 2-4.
+    const int k0 = blockIdx.y * kchunk;
+    const int klen = min(kchunk, ncols - k0);
+    out += blockIdx.y * slab_stride;
     f32x16 acc[1][1];
     zero_acc(acc);
-    G::template run<true>(Wg, ldw, Z, ldz, m0, n0, nr, p, ncols, lds, rs, acc);
+    if (klen > 0) {
+        G::template run<true>(Wg + k0, ldw, Z + (long)k0 * ldz, ldz, m0, n0, nr, p, klen, lds, rs, acc);
+    } else {
+        if (threadIdx.x < GT) rs[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
     const int col = n0 + G::sub_col(0);
     if (col >= p) return;
 #pragma unroll
@@ -362,18 +422,36 @@ extern "C" int vgan_mmd_loss(const double* stats, const uint64_t* colkey, int n,
     return VGAN_OK;
 }
 
+extern "C" int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int ntiles, const uint64_t* colpart, int chunks,
+                                 uint64_t* colkey, int n, int d, float weight, double* stats, float* loss, float* loss_accum,
+                                 float accum_scale, uint64_t* step_counter, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(partial && tiles && ntiles > 0 && stats && loss && n > 0 && d > 0);
+    VGAN_CHECK_ARG(colpart == nullptr || (colkey != nullptr && chunks > 0));
+    hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial,
+                       reinterpret_cast<const TileDesc*>(tiles), ntiles, reinterpret_cast<const unsigned long long*>(colpart), chunks,
+                       reinterpret_cast<unsigned long long*>(colkey), n, d, weight, stats, loss, loss_accum, accum_scale,
+                       reinterpret_cast<unsigned long long*>(step_counter));
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
 extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr, int ncols, int p,
-                                 const float* mul, int ldmul, float* out, int ldo, vgan_stream_t stream) {
+                                 const float* mul, int ldmul, float* out, int ldo, int splits, int64_t slab_stride,
+                                 vgan_stream_t stream) {
     VGAN_CHECK_ARG(Wg && Z && out && nr > 0 && ncols > 0 && p > 0 && ldw >= ncols && ldz >= p && ldo >= p && wrow0 >= 0 &&
                    wrow0 + nr <= ncols);
     VGAN_CHECK_ARG(mul == nullptr || ldmul >= p);
+    VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (ncols % 4 == 0) && (ldw % 4 == 0) && (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Wg) && aligned16(Z);
-    dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT)), block(kBlock);
+    const int kchunk = ((ncols + splits - 1) / splits + GBK - 1) / GBK * GBK;  // whole K tiles per slice (keeps 16-byte alignment)
+    dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT), splits), block(kBlock);
     if (vec)
-        hipLaunchKernelGGL(mmd_backward_kernel<4>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo);
+        hipLaunchKernelGGL(mmd_backward_kernel<4>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo,
+                           kchunk, (long)slab_stride);
     else
-        hipLaunchKernelGGL(mmd_backward_kernel<1>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo);
+        hipLaunchKernelGGL(mmd_backward_kernel<1>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo,
+                           kchunk, (long)slab_stride);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

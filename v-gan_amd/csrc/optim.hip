@@ -16,15 +16,20 @@ __device__ __forceinline__ void adadelta_one(float& p, float g, float& v, float&
     p = fmaf(-lr, delta, p);
 }
 
+// g may be `nslabs` split-K slabs `slab_stride` apart: they are summed here in ascending order (one pass less)
 __global__ __launch_bounds__(kBlock) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
                                                          float* __restrict__ acc, long count, float lr, float rho, float eps,
-                                                         float wd, float gs, int vec) {
+                                                         float wd, float gs, int vec, int nslabs, long slab_stride) {
     const long stride = (long)gridDim.x * blockDim.x;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
         const long nv = count >> 2;
         for (long q = i; q < nv; q += stride) {
             float4 pv = reinterpret_cast<float4*>(p)[q], gv = reinterpret_cast<const float4*>(g)[q];
+            for (int sl = 1; sl < nslabs; ++sl) {
+                const float4 b = reinterpret_cast<const float4*>(g + sl * slab_stride)[q];
+                gv.x += b.x; gv.y += b.y; gv.z += b.z; gv.w += b.w;
+            }
             float4 vv = reinterpret_cast<float4*>(sq)[q], av = reinterpret_cast<float4*>(acc)[q];
             adadelta_one(pv.x, gv.x, vv.x, av.x, lr, rho, eps, wd, gs);
             adadelta_one(pv.y, gv.y, vv.y, av.y, lr, rho, eps, wd, gs);
@@ -35,9 +40,11 @@ __global__ __launch_bounds__(kBlock) void adadelta_kernel(float* __restrict__ p,
             reinterpret_cast<float4*>(acc)[q] = av;
         }
         i += nv << 2;  // tail
-        for (long q = i; q < count; q += stride) adadelta_one(p[q], g[q], sq[q], acc[q], lr, rho, eps, wd, gs);
-    } else {
-        for (long q = i; q < count; q += stride) adadelta_one(p[q], g[q], sq[q], acc[q], lr, rho, eps, wd, gs);
+    }
+    for (long q = i; q < count; q += stride) {
+        float gq = g[q];
+        for (int sl = 1; sl < nslabs; ++sl) gq += g[sl * slab_stride + q];
+        adadelta_one(p[q], gq, sq[q], acc[q], lr, rho, eps, wd, gs);
     }
 }
 
@@ -137,12 +144,13 @@ static inline int stream_grid(long work_items) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-extern "C" int vgan_adadelta_step(float* p, const float* g, float* sq_avg, float* acc_delta, int64_t count, float lr, float rho,
-                                  float eps, float weight_decay, float grad_scale, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(p && g && sq_avg && acc_delta && count > 0);
-    const int vec = aligned16(p) && aligned16(g) && aligned16(sq_avg) && aligned16(acc_delta);
+extern "C" int vgan_adadelta_step(float* p, const float* g, int nslabs, int64_t slab_stride, float* sq_avg, float* acc_delta,
+                                  int64_t count, float lr, float rho, float eps, float weight_decay, float grad_scale,
+                                  vgan_stream_t stream) {
+    VGAN_CHECK_ARG(p && g && sq_avg && acc_delta && count > 0 && nslabs >= 1 && (nslabs == 1 || slab_stride >= count));
+    const int vec = aligned16(p) && aligned16(g) && aligned16(sq_avg) && aligned16(acc_delta) && (nslabs == 1 || slab_stride % 4 == 0);
     hipLaunchKernelGGL(adadelta_kernel, dim3(stream_grid(vec ? (count + 3) / 4 : count)), dim3(kBlock), 0, (hipStream_t)stream, p, g,
-                       sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale, vec);
+                       sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale, vec, nslabs, (long)slab_stride);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -75,11 +75,114 @@ __global__ __launch_bounds__(kBlock) void mask_forward_kernel(const float* __res
     }
 }
 
+
+// ---- fast paths: d % 4 == 0 and d <= 1024: the whole row lives in registers (NT float4 per lane), every global
+// access is 16 bytes per lane, and each row is read exactly once.
+template <int NT>
+__global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
+                                                                 int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ U,
+                                                                 float* __restrict__ Zx, float* __restrict__ Zy, int ldz,
+                                                                 float* __restrict__ sqx, float* __restrict__ sqy, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int nq = d >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(logits + (long)i * ldl);
+    const float4* xr4 = reinterpret_cast<const float4*>(data + rows(i) * ldd);
+    float4 v[NT], xv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = lane + 64 * t;
+        const bool ok = q < nq;
+        v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        xv[t] = xr4[min(q, nq - 1)];
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) m = fmaxf(m, fmaxf(fmaxf(v[t].x, v[t].y), fmaxf(v[t].z, v[t].w)));
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        v[t].x = expf(v[t].x - m); v[t].y = expf(v[t].y - m); v[t].z = expf(v[t].z - m); v[t].w = expf(v[t].w - m);
+        sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);  // padded lanes hold exp(-inf) = 0
+    }
+    sum = wave_sum(sum);
+    const float tau = 1.0f / (float)d;
+    float nx = 0.f, ny = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = lane + 64 * t;
+        if (q < nq) {
+            float4 s4 = make_float4(v[t].x / sum, v[t].y / sum, v[t].z / sum, v[t].w / sum);
+            float4 u4 = make_float4(s4.x < tau ? s4.x : 1.f, s4.y < tau ? s4.y : 1.f, s4.z < tau ? s4.z : 1.f, s4.w < tau ? s4.w : 1.f);
+            float4 y4 = make_float4(u4.x * xv[t].x, u4.y * xv[t].y, u4.z * xv[t].z, u4.w * xv[t].w);
+            reinterpret_cast<float4*>(S + (long)i * d)[q] = s4;
+            if (U) reinterpret_cast<float4*>(U + (long)i * d)[q] = u4;
+            if (Zx) reinterpret_cast<float4*>(Zx + (long)i * ldz)[q] = xv[t];
+            reinterpret_cast<float4*>(Zy + (long)i * ldz)[q] = y4;
+            nx += (xv[t].x * xv[t].x + xv[t].y * xv[t].y) + (xv[t].z * xv[t].z + xv[t].w * xv[t].w);
+            ny += (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
+        }
+    }
+    nx = wave_sum(nx);
+    ny = wave_sum(ny);
+    if (lane == 0) {
+        if (sqx) sqx[i] = nx;
+        sqy[i] = ny;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void mask_backward_vec_kernel(const float* __restrict__ gU, int ldg, const float* __restrict__ S,
+                                                                  int lds, const unsigned long long* __restrict__ colkey,
+                                                                  float pen_weight, int row_offset, float* __restrict__ dlogits,
+                                                                  int ldo, int n, int d, int nslabs, long slab_stride) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int nq = d >> 2;
+    const float tau = 1.0f / (float)d;
+    const float pg = -pen_weight / (float)d;
+    const unsigned me = (unsigned)(row_offset + i);
+    float4 sv[NT], gs[NT];
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = min(lane + 64 * t, nq - 1);
+        const bool ok = lane + 64 * t < nq;
+        sv[t] = reinterpret_cast<const float4*>(S + (long)i * lds)[q];
+        float4 g = reinterpret_cast<const float4*>(gU + (long)i * ldg)[q];
+        for (int sl = 1; sl < nslabs; ++sl) {
+            const float4 b = reinterpret_cast<const float4*>(gU + sl * slab_stride + (long)i * ldg)[q];
+            g.x += b.x; g.y += b.y; g.z += b.z; g.w += b.w;
+        }
+        if (colkey != nullptr) {
+            const ulonglong2 k0 = reinterpret_cast<const ulonglong2*>(colkey)[2 * q], k1 = reinterpret_cast<const ulonglong2*>(colkey)[2 * q + 1];
+            if (colkey_row(k0.x) == me) g.x += pg;
+            if (colkey_row(k0.y) == me) g.y += pg;
+            if (colkey_row(k1.x) == me) g.z += pg;
+            if (colkey_row(k1.y) == me) g.w += pg;
+        }
+        gs[t] = make_float4(ok && sv[t].x < tau ? g.x : 0.f, ok && sv[t].y < tau ? g.y : 0.f, ok && sv[t].z < tau ? g.z : 0.f,
+                            ok && sv[t].w < tau ? g.w : 0.f);
+        dot += (gs[t].x * sv[t].x + gs[t].y * sv[t].y) + (gs[t].z * sv[t].z + gs[t].w * sv[t].w);
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = lane + 64 * t;
+        if (q < nq)
+            reinterpret_cast<float4*>(dlogits + (long)i * ldo)[q] =
+                make_float4(sv[t].x * (gs[t].x - dot), sv[t].y * (gs[t].y - dot), sv[t].z * (gs[t].z - dot), sv[t].w * (gs[t].w - dot));
+    }
+}
+
 // dlogits = S * (g_s - sum_j g_s S),  g_s = [S < 1/d] * (gU + penalty gradient at the column arg-max row)
 __global__ __launch_bounds__(kBlock) void mask_backward_kernel(const float* __restrict__ gU, int ldg, const float* __restrict__ S,
                                                               int lds, const unsigned long long* __restrict__ colkey,
                                                               float pen_weight, int row_offset, float* __restrict__ dlogits,
-                                                              int ldo, int n, int d) {
+                                                              int ldo, int n, int d, int nslabs, long slab_stride) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -88,19 +191,22 @@ __global__ __launch_bounds__(kBlock) void mask_backward_kernel(const float* __re
     const float* g = gU + (long)i * ldg;
     const float* s = S + (long)i * lds;
     const unsigned me = (unsigned)(row_offset + i);
+    // gU may arrive as split-K slabs of the MMD backward GEMM: the sum over slabs is taken here (fixed order)
+    auto grad = [&](int j) {
+        float gv = g[j];
+        for (int q = 1; q < nslabs; ++q) gv += g[q * slab_stride + j];
+        if (colkey != nullptr && colkey_row(colkey[j]) == me) gv += pg;
+        return gv;
+    };
     float dot = 0.f;
     for (int j = lane; j < d; j += 64) {
         const float sv = s[j];
-        float gv = g[j];
-        if (colkey != nullptr && colkey_row(colkey[j]) == me) gv += pg;
-        dot = fmaf(sv < tau ? gv : 0.f, sv, dot);
+        dot = fmaf(sv < tau ? grad(j) : 0.f, sv, dot);
     }
     dot = wave_sum(dot);
     for (int j = lane; j < d; j += 64) {
         const float sv = s[j];
-        float gv = g[j];
-        if (colkey != nullptr && colkey_row(colkey[j]) == me) gv += pg;
-        dlogits[(long)i * ldo + j] = sv * ((sv < tau ? gv : 0.f) - dot);
+        dlogits[(long)i * ldo + j] = sv * ((sv < tau ? grad(j) : 0.f) - dot);
     }
 }
 
@@ -179,8 +285,17 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
     VGAN_CHECK_ARG(logits && data && S && Zy && sqy && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
     VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && row_offset >= 0);
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
-    hipLaunchKernelGGL(mask_forward_kernel<true>, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream,
-                       logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d);
+    const dim3 grid((n + kRowsPerBlock - 1) / kRowsPerBlock), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (d % 4 == 0) && (d <= 1024) && (ldl % 4 == 0) && (ldd % 4 == 0) && (ldz % 4 == 0) && aligned16(logits) &&
+                     aligned16(data) && aligned16(S) && (U == nullptr || aligned16(U)) && (Zx == nullptr || aligned16(Zx)) && aligned16(Zy);
+    if (vec) {
+        const int nt = (d / 4 + 63) / 64;
+#define VGAN_LAUNCH_FWD(NT) hipLaunchKernelGGL(mask_forward_vec_kernel<NT>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d)
+        if (nt == 1) VGAN_LAUNCH_FWD(1); else if (nt == 2) VGAN_LAUNCH_FWD(2); else if (nt == 3) VGAN_LAUNCH_FWD(3); else VGAN_LAUNCH_FWD(4);
+#undef VGAN_LAUNCH_FWD
+    } else
+        hipLaunchKernelGGL(mask_forward_kernel<true>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -193,11 +308,23 @@ extern "C" int vgan_upper_softmax_forward(const float* logits, int ldl, float* S
     return VGAN_OK;
 }
 
-extern "C" int vgan_mask_backward(const float* gU, int ldg, const float* S, int lds, const uint64_t* colkey, float pen_weight,
-                                  int row_offset, float* dlogits, int ldo, int n, int d, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(gU && S && dlogits && n > 0 && d > 0 && ldg >= d && lds >= d && ldo >= d);
-    hipLaunchKernelGGL(mask_backward_kernel, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream, gU,
-                       ldg, S, lds, reinterpret_cast<const unsigned long long*>(colkey), pen_weight, row_offset, dlogits, ldo, n, d);
+extern "C" int vgan_mask_backward(const float* gU, int ldg, int nslabs, int64_t slab_stride, const float* S, int lds,
+                                  const uint64_t* colkey, float pen_weight, int row_offset, float* dlogits, int ldo, int n, int d,
+                                  vgan_stream_t stream) {
+    VGAN_CHECK_ARG(gU && S && dlogits && n > 0 && d > 0 && ldg >= d && lds >= d && ldo >= d && nslabs >= 1);
+    const dim3 grid((n + kRowsPerBlock - 1) / kRowsPerBlock), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned long long* ck = reinterpret_cast<const unsigned long long*>(colkey);
+    const bool vec = (d % 4 == 0) && (d <= 1024) && (ldg % 4 == 0) && (lds % 4 == 0) && (ldo % 4 == 0) && (slab_stride % 4 == 0) &&
+                     aligned16(gU) && aligned16(S) && aligned16(dlogits) && (colkey == nullptr || aligned16(colkey));
+    if (vec) {
+        const int nt = (d / 4 + 63) / 64;
+#define VGAN_LAUNCH_BWD(NT) hipLaunchKernelGGL(mask_backward_vec_kernel<NT>, grid, block, 0, st, gU, ldg, S, lds, ck, pen_weight, row_offset, dlogits, ldo, n, d, nslabs, (long)slab_stride)
+        if (nt == 1) VGAN_LAUNCH_BWD(1); else if (nt == 2) VGAN_LAUNCH_BWD(2); else if (nt == 3) VGAN_LAUNCH_BWD(3); else VGAN_LAUNCH_BWD(4);
+#undef VGAN_LAUNCH_BWD
+    } else
+        hipLaunchKernelGGL(mask_backward_kernel, grid, block, 0, st, gU, ldg, S, lds, ck, pen_weight, row_offset, dlogits, ldo, n, d, nslabs,
+                           (long)slab_stride);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -213,6 +340,15 @@ extern "C" int vgan_gather_rows(const float* data, int ldd, const int32_t* rows,
 }
 
 extern "C" int vgan_colmax_chunks(int n) { return n > 0 ? (n + kColChunkRows - 1) / kColChunkRows : 0; }
+
+extern "C" int vgan_colmax_partial(const float* S, int lds, int from_softmax, int row_offset, uint64_t* part, int n, int d,
+                                   vgan_stream_t stream) {
+    VGAN_CHECK_ARG(S && part && n > 0 && d > 0 && lds >= d);
+    hipLaunchKernelGGL(colmax_partial_kernel, dim3((d + 63) / 64, vgan_colmax_chunks(n)), dim3(kBlock), 0, (hipStream_t)stream, S,
+                       lds, row_offset, reinterpret_cast<unsigned long long*>(part), n, d, from_softmax);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
 
 extern "C" int vgan_colmax(const float* S, int lds, int from_softmax, int row_offset, uint64_t* part, uint64_t* colkey, int n,
                            int d, vgan_stream_t stream) {

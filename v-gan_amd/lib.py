@@ -22,7 +22,9 @@ SIGNATURES = {
     "vgan_reduce_slabs": (_i, [_p, _i64, _i, _p, _i64, _p]),
     "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
     "vgan_gather_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
-    "vgan_mask_backward": (_i, [_p, _i, _p, _i, _p, _f, _i, _p, _i, _i, _i, _p]),
+    "vgan_mask_backward": (_i, [_p, _i, _i, _i64, _p, _i, _p, _f, _i, _p, _i, _i, _i, _p]),
+    "vgan_colmax_partial": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
+    "vgan_mmd_finalize": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _f, _p, _p, _p, _f, _p, _p]),
     "vgan_colmax_chunks": (_i, [_i]),
     "vgan_colmax": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p]),
     "vgan_mask_from_softmax": (_i, [_p, _i, _p, _i, _i, _i, _p]),
@@ -32,9 +34,9 @@ SIGNATURES = {
     "vgan_mmd_reduce": (_i, [_p, _p, _i, _p, _i, _p]),
     "vgan_mmd_set_bandwidth": (_i, [_p, _i, _p, _p]),
     "vgan_mmd_loss": (_i, [_p, _p, _i, _i, _f, _p, _p, _f, _p, _p]),
-    "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
-    "vgan_adadelta_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
+    "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_noise_normal": (_i, [_p, _i64, _u64, _p, _u64, _p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }

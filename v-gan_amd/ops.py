@@ -113,10 +113,11 @@ class HipOps:
         _lib.check(self.lib.vgan_upper_softmax_forward(_ptr(logits), logits.stride(0), _ptr(S), _ptr(U), n, d, self._stream()),
                    "vgan_upper_softmax_forward")
 
-    def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits):
+    def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits, nslabs=1, slab_stride=0):
         _mat(gU, "gU"), _mat(S, "S"), _mat(dlogits, "dlogits")
         n, d = S.shape
-        _lib.check(self.lib.vgan_mask_backward(_ptr(gU), gU.stride(0), _ptr(S), S.stride(0), _ptr(colkey), float(pen_weight),
+        _lib.check(self.lib.vgan_mask_backward(_ptr(gU), gU.stride(0), int(nslabs), int(slab_stride), _ptr(S), S.stride(0),
+                                               _ptr(colkey), float(pen_weight),
                                                int(row_offset), _ptr(dlogits), dlogits.stride(0), n, d, self._stream()),
                    "vgan_mask_backward")
 
@@ -126,6 +127,19 @@ class HipOps:
         assert part.dtype == torch.int64 and colkey.dtype == torch.int64 and part.numel() >= self.colmax_chunks(n) * d
         _lib.check(self.lib.vgan_colmax(_ptr(S), S.stride(0), int(bool(from_softmax)), int(row_offset), _ptr(part), _ptr(colkey), n, d, self._stream()),
                    "vgan_colmax")
+
+    def colmax_partial(self, S, row_offset, part, from_softmax=True):
+        _mat(S, "S")
+        n, d = S.shape
+        assert part.dtype == torch.int64 and part.numel() >= self.colmax_chunks(n) * d
+        _lib.check(self.lib.vgan_colmax_partial(_ptr(S), S.stride(0), int(bool(from_softmax)), int(row_offset), _ptr(part), n, d,
+                                                self._stream()), "vgan_colmax_partial")
+
+    def mmd_finalize(self, partial, tiles, colpart, chunks, colkey, n, d, weight, stats, loss, loss_accum=None, accum_scale=1.0,
+                     step_counter=None):
+        _lib.check(self.lib.vgan_mmd_finalize(_ptr(partial), _ptr(tiles), tiles.shape[0], _ptr(colpart), int(chunks), _ptr(colkey),
+                                              int(n), int(d), float(weight), _ptr(stats), _ptr(loss), _ptr(loss_accum),
+                                              float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_finalize")
 
     def mask_from_softmax(self, S, U):
         _mat(S, "S"), _mat(U, "U")
@@ -160,17 +174,21 @@ class HipOps:
         _lib.check(self.lib.vgan_mmd_loss(_ptr(stats), _ptr(colkey), int(n), int(d), float(weight), _ptr(loss), _ptr(loss_accum),
                                           float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_loss")
 
-    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out):
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0):
+        """splits > 1: `out` is slab 0 of `splits` partial slabs `slab_stride` elements apart."""
         _mat(Wg, "Wg"), _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         _lib.check(self.lib.vgan_mmd_backward(_ptr(Wg), Wg.stride(0), _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(ncols), int(p),
-                                              _ptr(mul), ldmul, _ptr(out), out.stride(0), self._stream()), "vgan_mmd_backward")
+                                              _ptr(mul), ldmul, _ptr(out), out.stride(0), int(splits), int(slab_stride),
+                                              self._stream()), "vgan_mmd_backward")
 
     # ---- optimiser / noise / misc ----------------------------------------------------------------
-    def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
-        for t, nm in ((p, "p"), (g, "g"), (sq, "sq"), (acc, "acc")):
+    def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
+        """nslabs > 1: `g` is slab 0 of split-K gradient slabs `slab_stride` apart, summed inside the kernel."""
+        for t, nm in ((p, "p"), (sq, "sq"), (acc, "acc")):
             _vec(t, nm)
-        _lib.check(self.lib.vgan_adadelta_step(_ptr(p), _ptr(g), _ptr(sq), _ptr(acc), p.numel(), float(lr), float(rho), float(eps),
+        _lib.check(self.lib.vgan_adadelta_step(_ptr(p), _ptr(g), int(nslabs), int(slab_stride), _ptr(sq), _ptr(acc), p.numel(),
+                                               float(lr), float(rho), float(eps),
                                                float(weight_decay), float(grad_scale), self._stream()), "vgan_adadelta_step")
 
     def noise_normal(self, z, seed, step_counter, stream_id=0):

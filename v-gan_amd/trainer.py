@@ -108,12 +108,31 @@ class NoKLStepEngine:
         self.Z = torch.zeros(2 * n, dp, **f32)
         self.sqn = torch.zeros(2 * n, **f32)
         self.Wg = torch.zeros(nl, 2 * n, **f32)
-        self.gU = torch.zeros(nl, dp, **f32)
+        # the backward GEMM contracts over the 2n rows of Z: sliced so that every SIMD holds several waves; the
+        # partial slabs are summed by the mask-backward kernel
+        import os
+        self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", "2")))
+        self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
+        self.gU = self.gU_slabs[0]
         self.dlogits = torch.zeros(nl, d, **f32)
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev)
-        self.tiles_cal = self.tiles
         self.partial = torch.zeros(self.tiles.shape[0], 4, **f32)
+        # The XX block only feeds the loss value, never the gradient: on one GPU it is launched from its own tile
+        # table on a side stream so that it fills the CUs the gradient path (XY/YY tiles -> backward GEMM) leaves idle.
+        # Measured on MI355X / ROCm 7.2 (c3): the fork/join graph is SLOWER than the plain chain (357 vs 313 us/step) --
+        # every cross-stream edge of a replayed HIP graph costs more than the overlap returns -- so it is opt-in.
+        import os
+        self.concurrent = bool(data.is_cuda and world == 1 and os.environ.get("VGAN_CONCURRENT", "0") not in ("0", ""))
+        self.concurrent_dw = os.environ.get("VGAN_CONCURRENT", "0") in ("1", "dw")
+        self.concurrent_xx = os.environ.get("VGAN_CONCURRENT", "0") in ("1", "xx")
+        if self.concurrent:
+            slot = (self.tiles[:, 4] & 3)
+            self.tiles_xx = self.tiles[slot == 0].contiguous()
+            self.tiles_g = self.tiles[slot != 0].contiguous()
+            self.partial_xx = torch.zeros(self.tiles_xx.shape[0], 4, **f32)
+            self.partial_g = torch.zeros(self.tiles_g.shape[0], 4, **f32)
+            self.side = [torch.cuda.Stream(device=self.dev) for _ in range(2)]
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
         self.has_bw = False
@@ -181,38 +200,115 @@ class NoKLStepEngine:
     def _loss_backward_update(self):
         ops, n, nl, lo, d = self.ops, self.n, self.nl, self.lo, self.d
         dist = self._collect() if self.world > 1 else None
-        ops.colmax(self.S, lo, self.colpart, self.colkey, True)
-        if dist:
+        gstride = nl * self.dp
+        if dist is None:
+            ops.colmax_partial(self.S, lo, self.colpart, True)
+            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
+            ops.mmd_finalize(self.partial, self.tiles, self.colpart, ops.colmax_chunks(nl), self.colkey, n, d, self.pen, self.stats,
+                             self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+        else:
+            ops.colmax(self.S, lo, self.colpart, self.colkey, True)
             dist.all_reduce(self.colkey, op=dist.ReduceOp.MAX, group=self.group)
-        ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
-        ops.mmd_reduce(self.partial, self.tiles, self.stats, True)
-        if dist:
+            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
+            ops.mmd_reduce(self.partial, self.tiles, self.stats, True)
             dist.all_reduce(self.stats, group=self.group)
-        ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
-        ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU)
-        ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits)
+            ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+        ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride)
+        ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         g = self.dlogits
         for k in (3, 2, 1, 0):
             ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
             if k:
                 ops.linear_backward_input(g, self.W[k], self.dacts[k])
                 g = self.dacts[k]
+        if dist:
+            if self.splits > 1:
+                ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
+            dist.all_reduce(self.fp.grad, group=self.group)
+            ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0)
+        elif self.splits > 1:  # single rank: Adadelta sums the slabs itself
+            ops.adadelta_step(self.fp.flat, self.gslab[0], self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0,
+                              self.splits, self.fp.total)
+        else:
+            ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0)
+
+    def grad_view(self, k):
+        """Gradient of parameter tensor k as of the last step (sums the split-K slabs if they were not reduced)."""
+        if self.world == 1 and self.splits > 1:
+            return sum(self.fp.view(self.gslab[sl], k) for sl in range(self.splits))
+        return self.fp.view(self.fp.grad, k)
+
+    def _loss_backward_update_concurrent(self):
+        """Single-GPU step tail as a fork/join graph over three streams (captured into the same HIP graph):
+             main : gram(XY,YY) -> backward GEMM -> mask backward -> dh chain -> slab reduce -> Adadelta
+             side0: column arg-max, gram(XX) -> block sums -> loss           (joins at the end of the step)
+             side1: the four weight-gradient GEMMs, each as soon as its dy exists
+        Independent kernels overlap, and the short or under-filled ones (XX tiles, dW GEMMs) run in the holes of
+        the long ones (528 Gram tiles / 208 backward tiles do not divide 256 CUs)."""
+        ops, n, d = self.ops, self.n, self.d
+        main = torch.cuda.current_stream()
+        s0, s1 = self.side
+        if self.concurrent_xx:
+            s0.wait_stream(main)
+            with torch.cuda.stream(s0):
+                ops.colmax(self.S, 0, self.colpart, self.colkey, True)
+                ev_colmax = torch.cuda.Event()
+                ev_colmax.record(s0)
+                ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles_xx, False, None, 0, self.partial_xx)
+            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles_g, False, self.Wg, n, self.partial_g)
+            ev_gram = torch.cuda.Event()
+            ev_gram.record(main)
+            with torch.cuda.stream(s0):
+                s0.wait_event(ev_gram)
+                ops.mmd_reduce(self.partial_xx, self.tiles_xx, self.stats, True)
+                ops.mmd_reduce(self.partial_g, self.tiles_g, self.stats, False)
+                ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+            ops.mmd_backward(self.Wg, self.Z, n, n, 2 * n, self.dp, self.Z[:n], self.gU, self.bsplits, n * self.dp)
+            main.wait_event(ev_colmax)
+        else:
+            ops.colmax(self.S, 0, self.colpart, self.colkey, True)
+            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n, self.partial)
+            ops.mmd_reduce(self.partial, self.tiles, self.stats, True)
+            ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+            ops.mmd_backward(self.Wg, self.Z, n, n, 2 * n, self.dp, self.Z[:n], self.gU, self.bsplits, n * self.dp)
+        ops.mask_backward(self.gU, self.S, self.colkey, self.pen, 0, self.dlogits, self.bsplits, n * self.dp)
+        g = self.dlogits
+        for k in (3, 2, 1, 0):
+            if self.concurrent_dw:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(s1):
+                    s1.wait_event(ev)
+                    ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
+            else:
+                ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
+            if k:
+                ops.linear_backward_input(g, self.W[k], self.dacts[k])
+                g = self.dacts[k]
+        if self.concurrent_dw:
+            main.wait_stream(s1)
         if self.splits > 1:
             ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
-        if dist:
-            dist.all_reduce(self.fp.grad, group=self.group)
         ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0)
+        if self.concurrent_xx:
+            main.wait_stream(s0)
 
     def _step_body(self):
         self._forward()
-        self._loss_backward_update()
+        if self.concurrent:
+            self._loss_backward_update_concurrent()
+        else:
+            self._loss_backward_update()
 
     def step(self):
         """Runs one training step asynchronously.  The first step also calibrates the bandwidth."""
         if not self.has_bw:
             self._forward()
             self._calibrate()
-            self._loss_backward_update()
+            if self.concurrent:
+                self._loss_backward_update_concurrent()
+            else:
+                self._loss_backward_update()
         elif self.use_graph:
             if self.graph is None:
                 self._capture()
