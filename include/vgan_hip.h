@@ -39,19 +39,23 @@ const char* vgan_last_error(void);
  * src/models/Detector.py:8-13,24-29: nn.Linear == addmm; autograd: two mm per layer)
  *   W is PyTorch layout [out, in].
  * ------------------------------------------------------------------------------------------- */
-/* y[n,out] = x[n,in] . W^T + b            (b may be NULL) */
-int vgan_linear_forward(const float* x, int ldx, const float* W, int ldw, const float* b,
-                        float* y, int ldy, int n, int in, int out, vgan_stream_t stream);
+/* y[n,out] = x[n,in] . W^T + b            (b may be NULL).
+ * x may be given as x_nslabs partial slabs x_slab_stride elements apart (a split-K result that was
+ * not reduced yet): they are summed, in ascending order, while the operand is staged. */
+int vgan_linear_forward(const float* x, int ldx, int x_nslabs, int64_t x_slab_stride, const float* W,
+                        int ldw, const float* b, float* y, int ldy, int n, int in, int out,
+                        vgan_stream_t stream);
 /* dx[n,in] = dy[n,out] . W */
 int vgan_linear_backward_input(const float* dy, int lddy, const float* W, int ldw,
                                float* dx, int lddx, int n, int in, int out, vgan_stream_t stream);
 /* dW[out,in] = dy^T . x ;  db[out] = column sums of dy   (db may be NULL).
  * splits > 1: the batch rows are cut into `splits` slices and slice s writes its PARTIAL result to
  * dW + s*slab_stride / db + s*slab_stride (elements); sum the slabs with vgan_reduce_slabs.  The
- * contraction runs over the batch while the outputs are small, so slicing is what fills the chip. */
-int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx,
-                                float* dW, int lddw, float* db, int n, int in, int out,
-                                int splits, int64_t slab_stride, vgan_stream_t stream);
+ * contraction runs over the batch while the outputs are small, so slicing is what fills the chip.
+ * x may itself be given as x_nslabs unreduced slabs (see vgan_linear_forward). */
+int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx, int x_nslabs,
+                                int64_t x_slab_stride, float* dW, int lddw, float* db, int n, int in,
+                                int out, int splits, int64_t slab_stride, vgan_stream_t stream);
 /* dst[i] = sum over s < nslabs of src[s*slab_stride + i], in ascending s (bitwise reproducible) */
 int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nslabs, float* dst, int64_t count,
                       vgan_stream_t stream);
@@ -177,8 +181,29 @@ int vgan_adadelta_step(float* p, const float* g, int nslabs, int64_t slab_stride
  * Noise feed  (src/vgan.py:610 `noise_tensor.normal_()`): standard normals from a counter-based
  * Philox4x32-10 stream + Box-Muller, keyed by (seed, *step_counter); replay-safe under HIP graphs.
  * ------------------------------------------------------------------------------------------- */
-int vgan_noise_normal(float* z, int64_t count, uint64_t seed, const uint64_t* step_counter,
-                      uint64_t stream_id, vgan_stream_t stream);
+/* z is [rows, cols] with row stride ld; element (r,c) is draw number r*cols + c of the stream, so the
+ * values do not depend on ld.  ones_col >= cols (or -1): column that is set to 1.0 in every row (the
+ * homogeneous coordinate of the collapsed generator chain). */
+int vgan_noise_normal(float* z, int rows, int cols, int ld, int ones_col, uint64_t seed,
+                      const uint64_t* step_counter, uint64_t stream_id, vgan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generator_big has NO activation between its four Linear layers (src/models/Generator.py:61-66),
+ * so in homogeneous coordinates the chain is a product of matrices Wt_k = [[W_k, b_k],[0, 1]]:
+ *   logits = [z|1] . (Wt_4 Wt_3 Wt_2 Wt_1)^T   and   dWt_k = (Wt_{k+1..4}^T dlogits^T [z|1]) . (Wt_{k-1..1})^T,
+ * i.e. every product has an inner or outer dimension of L+1 instead of the batch: ~0.2 GFLOP instead
+ * of 2.5 GFLOP per step at d=784.  The products run on vgan_linear_*; this entry point moves the
+ * parameters/gradients between the PyTorch layout and the packed one in a single launch.
+ * desc: device table, 8 int64 per layer {W ptr, b ptr, packed ptr, out, in, ldw, ldp, 0};
+ * packed is [out+1, in+1] with row stride ldp.  unpack != 0: packed -> (W, b) (rows < out only).
+ * max_elems: the largest (out+1)*(in+1) in the table (sizes the grid). */
+int vgan_homogeneous_pack(const int64_t* desc, int count, int max_elems, int unpack, vgan_stream_t stream);
+/* Adadelta for that chain without pack/unpack launches: the gradient of flat element i is
+ * g_packed[pmap[i]] and the updated parameter is also stored to w_packed[pmap[i]] (pmap[i] < 0: layout
+ * padding, skipped).  Same update rule as vgan_adadelta_step. */
+int vgan_adadelta_step_packed(float* p, const int32_t* pmap, const float* g_packed, float* w_packed,
+                              float* sq_avg, float* acc_delta, int64_t count, float lr, float rho,
+                              float eps, float weight_decay, float grad_scale, vgan_stream_t stream);
 
 /* sum of squared differences: out[0] (+)= scale * sum((a-b)^2)  -- `__distance(x,y,'L2')`,
  * src/vgan.py:58-59, and its gradient  ga (+)= gscale*(a-b), gb (+)= -gscale*(a-b). */

@@ -33,13 +33,21 @@ class CpuOps:
         return self.lib.vgan_colmax_chunks(n)
 
     # ---- Linear
-    def linear_forward(self, x, W, b, y):
+    @staticmethod
+    def _sum_slabs(x, nslabs, stride):
+        if nslabs == 1:
+            return x
+        return sum(torch.as_strided(x, x.shape, x.stride(), x.storage_offset() + q * stride) for q in range(nslabs))
+
+    def linear_forward(self, x, W, b, y, x_nslabs=1, x_slab_stride=0):
+        x = self._sum_slabs(x, x_nslabs, x_slab_stride)
         y.copy_(torch.as_tensor(_np(x).astype(np.float64) @ _np(W).astype(np.float64).T + (_np(b) if b is not None else 0)))
 
     def linear_backward_input(self, dy, W, dx):
         dx.copy_(torch.as_tensor(_np(dy).astype(np.float64) @ _np(W).astype(np.float64)))
 
-    def linear_backward_params(self, dy, x, dW, db, splits=1, slab_stride=0):
+    def linear_backward_params(self, dy, x, dW, db, splits=1, slab_stride=0, x_nslabs=1, x_slab_stride=0):
+        x = self._sum_slabs(x, x_nslabs, x_slab_stride)
         n = dy.shape[0]
         if splits == 1:
             dW.copy_(torch.as_tensor(_np(dy).astype(np.float64).T @ _np(x).astype(np.float64)))
@@ -222,7 +230,30 @@ class CpuOps:
         sq.copy_(torch.as_tensor(sn))
         acc.copy_(torch.as_tensor(an))
 
-    def noise_normal(self, z, seed, step_counter, stream_id=0):
+    def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+        m = pmap.long()
+        live = m >= 0
+        g = torch.zeros_like(p)
+        g[live] = g_packed[m[live]]
+        self.adadelta_step(p, g, sq, acc, lr, rho, eps, weight_decay, grad_scale)
+        w_packed[m[live]] = p[live]
+
+    def noise_normal(self, z, seed, step_counter, stream_id=0, cols=None, ones_col=-1):
         g = torch.Generator()
         g.manual_seed((int(seed) * 1000003 + int(step_counter.item()) * 7919 + int(stream_id)) % (2 ** 63))
-        z.copy_(torch.randn(z.shape, generator=g))
+        cols = z.shape[1] if cols is None else cols
+        z[:, :cols].copy_(torch.randn(z.shape[0], cols, generator=g))
+        if ones_col >= 0:
+            z[:, ones_col] = 1.0
+
+    def homogeneous_pack(self, layers, unpack=False):
+        for W, b, P in layers:
+            out, kin = W.shape
+            if unpack:
+                W.copy_(P[:out, :kin])
+                b.copy_(P[:out, kin])
+            else:
+                P[:out, :kin].copy_(W)
+                P[:out, kin].copy_(b)
+                P[out, :kin + 1] = 0.0
+                P[out, kin] = 1.0

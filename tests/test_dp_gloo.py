@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, steps, out_dir):
+def _worker(rank, world, port, steps, out_dir, mode):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,7 +29,7 @@ def _worker(rank, world, port, steps, out_dir):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = load_golden("f3_traj_c1.npz")
-    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["data"], 128, 10, rank=rank, world=world,
+    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["data"], 128, 10, rank=rank, world=world, generator_mode=mode,
                          lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
     losses = []
     for t in range(steps):
@@ -43,10 +43,10 @@ def _worker(rank, world, port, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_row_sharded_dp_matches_single_process(world, tmp_path):
+@pytest.mark.parametrize("world,mode", [(2, "collapsed"), (4, "collapsed"), (2, "layered")])
+def test_row_sharded_dp_matches_single_process(world, mode, tmp_path):
     steps = 25
-    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mode), nprocs=world, join=True)
     g = load_golden("f3_traj_c1.npz")
     outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for o in outs:

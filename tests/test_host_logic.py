@@ -53,11 +53,12 @@ def test_flat_params_layout_and_views():
     assert list(gen.state_dict()) == [f"main.{k}.{w}" for k in range(4) for w in ("weight", "bias")]
 
 
+@pytest.mark.parametrize("mode", ["collapsed", "layered"])
 @pytest.mark.parametrize("cfg", ["c1", "c2"])
-def test_engine_two_steps_vs_reference_fixture(cfg):
+def test_engine_two_steps_vs_reference_fixture(cfg, mode):
     g = load_golden(f"f2_step_{cfg}.npz")
     n = g["batch"].shape[0]
-    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], n, 1)
+    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], n, 1, generator_mode=mode)
     eng.set_epoch_batches(torch.arange(n).view(1, n))
     for step in range(2):
         eng.set_noise(torch.as_tensor(g["noise"]))

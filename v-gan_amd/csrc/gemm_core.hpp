@@ -38,11 +38,15 @@ typedef __attribute__((address_space(3))) f32x4 lds_f4;  // ext-vector: plain as
 // load(k0) issues UNCONDITIONAL loads from clamped, always-valid addresses and store() zeroes what was out
 // of range: a guarded load compiles to a branch whose merge forces s_waitcnt vmcnt(0) right after issue,
 // which would serialise the prefetch with the MFMAs it is meant to hide under.
-template <int BMN, int BK, int LAYOUT, int VEC>
+// SL: the operand is given as `nslabs` partial slabs `slab_stride` elements apart (split-K output of a previous
+// product); load() sums them in ascending order, which removes a separate reduction launch.
+template <int BMN, int BK, int LAYOUT, int VEC, bool SL = false>
 struct Stager;
 
-template <int BMN, int BK>
-struct Stager<BMN, BK, KC, 4> {
+template <int BMN, int BK, bool SL>
+struct Stager<BMN, BK, KC, 4, SL> {
+    int nslabs = 1;
+    long slab_stride = 0;
     static constexpr int NV = BMN * BK / 4 / kBlock;
     static_assert(NV >= 1, "tile too small");
     float4 v[NV];
@@ -68,6 +72,11 @@ struct Stager<BMN, BK, KC, 4> {
         for (int r = 0; r < NV; ++r) {
             ok[r] = rowok[r] && (k < K);
             v[r] = *reinterpret_cast<const float4*>(rowp[r] + kc);
+            if constexpr (SL)
+                for (int sl = 1; sl < nslabs; ++sl) {
+                    const float4 t = *reinterpret_cast<const float4*>(rowp[r] + sl * slab_stride + kc);
+                    v[r].x += t.x; v[r].y += t.y; v[r].z += t.z; v[r].w += t.w;
+                }
         }
     }
     __device__ __forceinline__ void store(lds_f* lds) {
@@ -95,8 +104,10 @@ struct Stager<BMN, BK, KC, 4> {
     }
 };
 
-template <int BMN, int BK>
-struct Stager<BMN, BK, KC, 1> {
+template <int BMN, int BK, bool SL>
+struct Stager<BMN, BK, KC, 1, SL> {
+    int nslabs = 1;
+    long slab_stride = 0;
     static constexpr int NV = BMN * BK / kBlock;
     float v[NV];
     const float* rowp[NV];
@@ -121,6 +132,8 @@ struct Stager<BMN, BK, KC, 1> {
         for (int r = 0; r < NV; ++r) {
             ok[r] = rowok[r] && (k < K);
             v[r] = rowp[r][kc];
+            if constexpr (SL)
+                for (int sl = 1; sl < nslabs; ++sl) v[r] += rowp[r][sl * slab_stride + kc];
         }
     }
     __device__ __forceinline__ void store(lds_f* lds) {
@@ -147,8 +160,10 @@ struct Stager<BMN, BK, KC, 1> {
     }
 };
 
-template <int BMN, int BK>
-struct Stager<BMN, BK, MC, 4> {
+template <int BMN, int BK, bool SL>
+struct Stager<BMN, BK, MC, 4, SL> {
+    int nslabs = 1;
+    long slab_stride = 0;
     static constexpr int NV = BMN * BK / 4 / kBlock;
     static_assert(NV >= 1, "tile too small");
     static_assert(kBlock % (BMN / 4) == 0, "mq must be fixed per thread");
@@ -176,6 +191,11 @@ struct Stager<BMN, BK, MC, 4> {
             const int k = k0 + krow[r];
             ok[r] = colok && (k < K);
             v[r] = *reinterpret_cast<const float4*>(colp + (long)min(k, K - 1) * ld);
+            if constexpr (SL)
+                for (int sl = 1; sl < nslabs; ++sl) {
+                    const float4 t = *reinterpret_cast<const float4*>(colp + sl * slab_stride + (long)min(k, K - 1) * ld);
+                    v[r].x += t.x; v[r].y += t.y; v[r].z += t.z; v[r].w += t.w;
+                }
         }
     }
     __device__ __forceinline__ void store(lds_f* lds) {
@@ -207,8 +227,10 @@ struct Stager<BMN, BK, MC, 4> {
     }
 };
 
-template <int BMN, int BK>
-struct Stager<BMN, BK, MC, 1> {
+template <int BMN, int BK, bool SL>
+struct Stager<BMN, BK, MC, 1, SL> {
+    int nslabs = 1;
+    long slab_stride = 0;
     static constexpr int NV = BMN * BK / kBlock;
     static_assert(kBlock % BMN == 0, "m must be fixed per thread");
     float v[NV];
@@ -235,6 +257,8 @@ struct Stager<BMN, BK, MC, 1> {
             const int k = k0 + krow[r];
             ok[r] = colok && (k < K);
             v[r] = colp[(long)min(k, K - 1) * ld];
+            if constexpr (SL)
+                for (int sl = 1; sl < nslabs; ++sl) v[r] += colp[sl * slab_stride + (long)min(k, K - 1) * ld];
         }
     }
     __device__ __forceinline__ void store(lds_f* lds) {
@@ -266,7 +290,8 @@ struct Stager<BMN, BK, MC, 1> {
 };
 
 // ---- the tile main loop --------------------------------------------------------------------
-template <int BM, int BN, int BK, int LA, int LB, int VEC>
+// SLABS bit 0: the A operand arrives as slabs, bit 1: the B operand does (see Stager).
+template <int BM, int BN, int BK, int LA, int LB, int VEC, int SLABS = 0>
 struct GemmTile {
     static constexpr int WM = BM / 64, WN = BN / 64;
     static constexpr int kImgA = (LA == KC) ? BM * (BK + kPad) : BK * (BM + kPad);  // floats per buffer
@@ -291,7 +316,7 @@ struct GemmTile {
     template <bool SIDE_A>
     __device__ static __forceinline__ void run(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
                                                int m0, int n0, int M, int N, int K, float* lds_generic, float* side_generic,
-                                               f32x16 (&acc)[WM][WN]) {
+                                               f32x16 (&acc)[WM][WN], int nslabs = 1, long slab_stride = 0) {
         lds_f* lds = (lds_f*)lds_generic;
         lds_f* side_lds = (lds_f*)side_generic;
         const int tid = threadIdx.x;
@@ -301,11 +326,13 @@ struct GemmTile {
         lds_f* const sA0 = lds;  // buffers: A0 | A1 | B0 | B1
         lds_f* const sB0 = lds + 2 * kImgA;
 
-        using SG = Stager<BM, BK, LA, VEC>;
+        using SG = Stager<BM, BK, LA, VEC, (SLABS & 1) != 0>;
         SG ga;
-        Stager<BN, BK, LB, VEC> gb;
+        Stager<BN, BK, LB, VEC, (SLABS & 2) != 0> gb;
         ga.init(A, lda, m0, M, K, tid);
         gb.init(B, ldb, n0, N, K, tid);
+        if constexpr (SLABS & 1) { ga.nslabs = nslabs; ga.slab_stride = slab_stride; }
+        if constexpr (SLABS & 2) { gb.nslabs = nslabs; gb.slab_stride = slab_stride; }
         typename SG::Side side[SG::NV];
         if constexpr (SIDE_A) {
 #pragma unroll

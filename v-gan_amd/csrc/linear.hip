@@ -8,16 +8,16 @@ namespace vgan {
 constexpr int LBM = 64, LBN = 64, LBK = 32;
 
 // y = x . W^T + b           A = x (KC), B = W (KC)
-template <int VEC>
+template <int VEC, bool XSL>
 __global__ __launch_bounds__(kBlock, 2) void linear_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                               int ldw, const float* __restrict__ b, float* __restrict__ y,
-                                                              int ldy, int n, int in, int out) {
-    using G = GemmTile<LBM, LBN, LBK, KC, KC, VEC>;
+                                                              int ldy, int n, int in, int out, int x_nslabs, long x_slab_stride) {
+    using G = GemmTile<LBM, LBN, LBK, KC, KC, VEC, XSL ? 1 : 0>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
     f32x16 acc[G::WM][G::WN];
     zero_acc(acc);
-    G::template run<false>(x, ldx, W, ldw, m0, n0, n, out, in, lds, nullptr, acc);
+    G::template run<false>(x, ldx, W, ldw, m0, n0, n, out, in, lds, nullptr, acc, x_nslabs, x_slab_stride);
     const int col = n0 + G::sub_col(0);
     const float bias = (b != nullptr && col < out) ? b[col] : 0.f;
 #pragma unroll
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(kBlock, 2) void linear_bwd_input_kernel(const float
 // small, so one launch needs the row range cut into `kchunk`-row slices to fill 256 CUs; slice s writes its
 // partial result into slab s (dW + s*slab_stride, db + s*slab_stride), summed afterwards by vgan_reduce_slabs
 // (fixed order: bitwise reproducible, no atomics).
-template <int VEC>
+template <int VEC, bool XSL>
 __global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_kernel(const float* __restrict__ dy, int lddy,
                                                                      const float* __restrict__ x, int ldx, float* __restrict__ dW,
                                                                      int lddw, float* __restrict__ db, int n, int in, int out,
-                                                                     int kchunk, long slab_stride) {
-    using G = GemmTile<LBM, LBN, LBK, MC, MC, VEC>;
+                                                                     int kchunk, long slab_stride, int x_nslabs, long x_slab_stride) {
+    using G = GemmTile<LBM, LBN, LBK, MC, MC, VEC, XSL ? 2 : 0>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float side[LBM];
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_kernel(const floa
         if (threadIdx.x < LBM) side[threadIdx.x] = 0.f;
         __syncthreads();
     } else if (do_bias)
-        G::template run<true>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc);
+        G::template run<true>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc, x_nslabs, x_slab_stride);
     else
-        G::template run<false>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc);
+        G::template run<false>(dy, lddy, x, ldx, m0, n0, out, in, n, lds, side, acc, x_nslabs, x_slab_stride);
     const int col = n0 + G::sub_col(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -92,15 +92,16 @@ static inline dim3 grid_for(int rows, int cols) { return dim3((cols + LBN - 1) /
 
 using namespace vgan;
 
-extern "C" int vgan_linear_forward(const float* x, int ldx, const float* W, int ldw, const float* b, float* y, int ldy, int n,
-                                   int in, int out, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(x && W && y && n > 0 && in > 0 && out > 0 && ldx >= in && ldw >= in && ldy >= out);
+extern "C" int vgan_linear_forward(const float* x, int ldx, int x_nslabs, int64_t x_slab_stride, const float* W, int ldw,
+                                   const float* b, float* y, int ldy, int n, int in, int out, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(x && W && y && n > 0 && in > 0 && out > 0 && ldx >= in && ldw >= in && ldy >= out && x_nslabs >= 1);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = (in % 4 == 0) && (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(x) && aligned16(W);
-    if (vec)
-        hipLaunchKernelGGL(linear_fwd_kernel<4>, grid_for(n, out), dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out);
-    else
-        hipLaunchKernelGGL(linear_fwd_kernel<1>, grid_for(n, out), dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out);
+    const bool vec = (in % 4 == 0) && (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(x) && aligned16(W) && (x_slab_stride % 4 == 0);
+    const long xs = (long)x_slab_stride;
+#define VGAN_FWD(V, S) hipLaunchKernelGGL((linear_fwd_kernel<V, S>), grid_for(n, out), dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out, x_nslabs, xs)
+    if (x_nslabs > 1) { if (vec) VGAN_FWD(4, true); else VGAN_FWD(1, true); }
+    else { if (vec) VGAN_FWD(4, false); else VGAN_FWD(1, false); }
+#undef VGAN_FWD
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -118,25 +119,26 @@ extern "C" int vgan_linear_backward_input(const float* dy, int lddy, const float
     return VGAN_OK;
 }
 
-extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, float* db,
-                                           int n, int in, int out, int splits, int64_t slab_stride, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(dy && x && dW && n > 0 && in > 0 && out > 0 && lddy >= out && ldx >= in && lddw >= in);
+extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx, int x_nslabs, int64_t x_slab_stride,
+                                           float* dW, int lddw, float* db, int n, int in, int out, int splits, int64_t slab_stride,
+                                           vgan_stream_t stream) {
+    VGAN_CHECK_ARG(dy && x && dW && n > 0 && in > 0 && out > 0 && lddy >= out && ldx >= in && lddw >= in && x_nslabs >= 1);
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride > 0));
     hipStream_t s = (hipStream_t)stream;
     // row slices are multiples of 4 rows so that every slice keeps the 16-byte alignment of the vector path
     int kchunk = (n + splits - 1) / splits;
     kchunk = (kchunk + 3) / 4 * 4;
     const int nz = (n + kchunk - 1) / kchunk;
-    const bool vec = (out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldx % 4 == 0) && aligned16(dy) && aligned16(x);
+    const bool vec = (out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldx % 4 == 0) && aligned16(dy) && aligned16(x) &&
+                     (x_slab_stride % 4 == 0);
     dim3 grid = grid_for(out, in);
     grid.z = splits;  // slices beyond nz see klen <= 0 and write zeros, so the reducer may always sum `splits` slabs
     (void)nz;
-    if (vec)
-        hipLaunchKernelGGL(linear_bwd_params_kernel<4>, grid, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in, out, kchunk,
-                           (long)slab_stride);
-    else
-        hipLaunchKernelGGL(linear_bwd_params_kernel<1>, grid, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in, out, kchunk,
-                           (long)slab_stride);
+    const long xs = (long)x_slab_stride;
+#define VGAN_BWP(V, S) hipLaunchKernelGGL((linear_bwd_params_kernel<V, S>), grid, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in, out, kchunk, (long)slab_stride, x_nslabs, xs)
+    if (x_nslabs > 1) { if (vec) VGAN_BWP(4, true); else VGAN_BWP(1, true); }
+    else { if (vec) VGAN_BWP(4, false); else VGAN_BWP(1, false); }
+#undef VGAN_BWP
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

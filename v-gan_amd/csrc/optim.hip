@@ -48,6 +48,26 @@ __global__ __launch_bounds__(kBlock) void adadelta_kernel(float* __restrict__ p,
     }
 }
 
+// Adadelta for the collapsed generator chain: the gradient of flat element i is read from the packed (homogeneous)
+// gradient image at pmap[i], and the updated parameter is ALSO written to the packed weight image at the same offset,
+// so neither an unpack launch before nor a pack launch after the optimiser is needed.  pmap[i] < 0: layout padding.
+__global__ __launch_bounds__(kBlock) void adadelta_packed_kernel(float* __restrict__ p, const int* __restrict__ pmap,
+                                                                const float* __restrict__ gpacked, float* __restrict__ wpacked,
+                                                                float* __restrict__ sq, float* __restrict__ acc, long count, float lr,
+                                                                float rho, float eps, float wd, float gs) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += stride) {
+        const int m = pmap[q];
+        if (m < 0) continue;
+        float pv = p[q], v = sq[q], a = acc[q];
+        adadelta_one(pv, gpacked[m], v, a, lr, rho, eps, wd, gs);
+        p[q] = pv;
+        sq[q] = v;
+        acc[q] = a;
+        wpacked[m] = pv;
+    }
+}
+
 // dst[i] = sum_s src[s*slab_stride + i], s ascending (fixed order)
 __global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const float* __restrict__ src, long slab_stride, int nslabs,
                                                              float* __restrict__ dst, long count, int vec) {
@@ -92,10 +112,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
 }
 __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
 
-__global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict__ z, long count, unsigned long long seed,
-                                                             const unsigned long long* __restrict__ step_counter,
+__global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict__ z, int rows, int cols, int ld, int ones_col,
+                                                             unsigned long long seed, const unsigned long long* __restrict__ step_counter,
                                                              unsigned long long stream_id) {
     const unsigned long long step = step_counter ? step_counter[0] : 0ull;
+    const long count = (long)rows * cols;
     const long nq = (count + 3) >> 2;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
         unsigned c[4] = {(unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)step, (unsigned)(step >> 32)};
@@ -110,8 +131,35 @@ __global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict_
             o[2 * h + 1] = r * sn;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (4 * q + e < count) z[4 * q + e] = o[e];
+        for (int e = 0; e < 4; ++e) {  // element index is row-major over [rows, cols], independent of ld
+            const long idx = 4 * q + e;
+            if (idx < count) z[(idx / cols) * ld + (idx % cols)] = o[e];
+        }
+    }
+    if (ones_col >= 0)  // homogeneous coordinate [z | 1] of the collapsed generator chain
+        for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) z[r * ld + ones_col] = 1.0f;
+}
+
+// Homogeneous packing of Linear layers: Wt = [[W, b], [0, 1]] (zero padded to multiples of 4), so that a chain of
+// bias-Linear layers is a chain of plain matrix products; unpack = the reverse for the gradients.
+// desc[8*k ..]: {W ptr, b ptr, packed ptr, rows(out), cols(in), ldw, ldp, unused}
+__global__ __launch_bounds__(kBlock) void homogeneous_pack_kernel(const long long* __restrict__ desc, int unpack) {
+    const long long* e = desc + 8 * blockIdx.y;
+    float* W = reinterpret_cast<float*>(e[0]);
+    float* b = reinterpret_cast<float*>(e[1]);
+    float* P = reinterpret_cast<float*>(e[2]);
+    const int rows = (int)e[3], cols = (int)e[4], ldw = (int)e[5], ldp = (int)e[6];
+    const long total = (long)(rows + 1) * (cols + 1);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / (cols + 1)), c = (int)(idx % (cols + 1));
+        if (unpack) {
+            if (r < rows) {
+                const float v = P[(long)r * ldp + c];
+                if (c < cols) W[(long)r * ldw + c] = v; else b[r] = v;
+            }
+        } else {
+            P[(long)r * ldp + c] = r < rows ? (c < cols ? W[(long)r * ldw + c] : b[r]) : (c == cols ? 1.0f : 0.0f);
+        }
     }
 }
 
@@ -155,6 +203,16 @@ extern "C" int vgan_adadelta_step(float* p, const float* g, int nslabs, int64_t 
     return VGAN_OK;
 }
 
+extern "C" int vgan_adadelta_step_packed(float* p, const int32_t* pmap, const float* g_packed, float* w_packed, float* sq_avg,
+                                         float* acc_delta, int64_t count, float lr, float rho, float eps, float weight_decay,
+                                         float grad_scale, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(p && pmap && g_packed && w_packed && sq_avg && acc_delta && count > 0);
+    hipLaunchKernelGGL(adadelta_packed_kernel, dim3(stream_grid(count)), dim3(kBlock), 0, (hipStream_t)stream, p, pmap, g_packed, w_packed,
+                       sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
 extern "C" int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nslabs, float* dst, int64_t count, vgan_stream_t stream) {
     VGAN_CHECK_ARG(src && dst && nslabs >= 1 && count > 0 && (nslabs == 1 || slab_stride >= count));
     const int vec = aligned16(src) && aligned16(dst) && (slab_stride % 4 == 0);
@@ -164,12 +222,21 @@ extern "C" int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nsla
     return VGAN_OK;
 }
 
-extern "C" int vgan_noise_normal(float* z, int64_t count, uint64_t seed, const uint64_t* step_counter, uint64_t stream_id,
-                                 vgan_stream_t stream) {
-    VGAN_CHECK_ARG(z && count > 0);
-    hipLaunchKernelGGL(noise_normal_kernel, dim3(stream_grid((count + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, z, (long)count,
-                       (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step_counter),
+extern "C" int vgan_noise_normal(float* z, int rows, int cols, int ld, int ones_col, uint64_t seed, const uint64_t* step_counter,
+                                 uint64_t stream_id, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(z && rows > 0 && cols > 0 && ld >= cols && ones_col < ld && (ones_col < 0 || ones_col >= cols));
+    const long count = (long)rows * cols;
+    hipLaunchKernelGGL(noise_normal_kernel, dim3(stream_grid((count + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, z, rows, cols, ld,
+                       ones_col, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step_counter),
                        (unsigned long long)stream_id);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_homogeneous_pack(const int64_t* desc, int count, int max_elems, int unpack, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(desc && count > 0 && count <= 64 && max_elems > 0);
+    hipLaunchKernelGGL(homogeneous_pack_kernel, dim3(stream_grid(max_elems), count), dim3(kBlock), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(desc), unpack);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

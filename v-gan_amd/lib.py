@@ -16,9 +16,9 @@ _u64 = ctypes.c_uint64
 SIGNATURES = {
     "vgan_abi_version": (_i, []),
     "vgan_last_error": (ctypes.c_char_p, []),
-    "vgan_linear_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "vgan_linear_forward": (_i, [_p, _i, _i, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_input": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
-    "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i64, _p]),
+    "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _i, _i64, _p, _i, _p, _i, _i, _i, _i, _i64, _p]),
     "vgan_reduce_slabs": (_i, [_p, _i64, _i, _p, _i64, _p]),
     "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
     "vgan_gather_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
@@ -37,7 +37,9 @@ SIGNATURES = {
     "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
-    "vgan_noise_normal": (_i, [_p, _i64, _u64, _p, _u64, _p]),
+    "vgan_noise_normal": (_i, [_p, _i, _i, _i, _i, _u64, _p, _u64, _p]),
+    "vgan_homogeneous_pack": (_i, [_p, _i, _i, _i, _p]),
+    "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 

@@ -55,13 +55,14 @@ class HipOps:
         return self.lib.vgan_colmax_chunks(n)
 
     # ---- Linear ------------------------------------------------------------------------------
-    def linear_forward(self, x, W, b, y):
+    def linear_forward(self, x, W, b, y, x_nslabs=1, x_slab_stride=0):
+        """x_nslabs > 1: `x` is slab 0 of unreduced split-K slabs `x_slab_stride` elements apart (summed while staged)."""
         _mat(x, "x"), _mat(W, "W"), _mat(y, "y")
         n, kin = x.shape
         out = W.shape[0]
         assert W.shape[1] == kin and y.shape == (n, out)
-        _lib.check(self.lib.vgan_linear_forward(_ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), _ptr(y), y.stride(0),
-                                                n, kin, out, self._stream()), "vgan_linear_forward")
+        _lib.check(self.lib.vgan_linear_forward(_ptr(x), x.stride(0), int(x_nslabs), int(x_slab_stride), _ptr(W), W.stride(0),
+                                                _ptr(b), _ptr(y), y.stride(0), n, kin, out, self._stream()), "vgan_linear_forward")
 
     def linear_backward_input(self, dy, W, dx):
         _mat(dy, "dy"), _mat(W, "W"), _mat(dx, "dx")
@@ -71,15 +72,16 @@ class HipOps:
         _lib.check(self.lib.vgan_linear_backward_input(_ptr(dy), dy.stride(0), _ptr(W), W.stride(0), _ptr(dx), dx.stride(0),
                                                        n, kin, out, self._stream()), "vgan_linear_backward_input")
 
-    def linear_backward_params(self, dy, x, dW, db, splits=1, slab_stride=0):
-        """splits > 1: dW/db are slab 0 of `splits` slabs `slab_stride` elements apart (partial sums)."""
+    def linear_backward_params(self, dy, x, dW, db, splits=1, slab_stride=0, x_nslabs=1, x_slab_stride=0):
+        """splits > 1: dW/db are slab 0 of `splits` slabs `slab_stride` elements apart (partial sums).
+        x_nslabs > 1: `x` itself is slab 0 of unreduced slabs (summed while staged)."""
         _mat(dy, "dy"), _mat(x, "x"), _mat(dW, "dW")
         n, out = dy.shape
         kin = x.shape[1]
         assert x.shape[0] == n and dW.shape == (out, kin)
-        _lib.check(self.lib.vgan_linear_backward_params(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dW), dW.stride(0),
-                                                        _ptr(db), n, kin, out, int(splits), int(slab_stride), self._stream()),
-                   "vgan_linear_backward_params")
+        _lib.check(self.lib.vgan_linear_backward_params(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), int(x_nslabs), int(x_slab_stride),
+                                                        _ptr(dW), dW.stride(0), _ptr(db), n, kin, out, int(splits), int(slab_stride),
+                                                        self._stream()), "vgan_linear_backward_params")
 
     def reduce_slabs(self, src, slab_stride, nslabs, dst):
         _vec(dst, "dst")
@@ -191,10 +193,40 @@ class HipOps:
                                                float(lr), float(rho), float(eps),
                                                float(weight_decay), float(grad_scale), self._stream()), "vgan_adadelta_step")
 
-    def noise_normal(self, z, seed, step_counter, stream_id=0):
-        _vec(z, "z")
-        _lib.check(self.lib.vgan_noise_normal(_ptr(z), z.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(step_counter), int(stream_id),
-                                              self._stream()), "vgan_noise_normal")
+    def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+        for t, nm in ((p, "p"), (sq, "sq"), (acc, "acc"), (g_packed, "g_packed"), (w_packed, "w_packed")):
+            _vec(t, nm)
+        _vec(pmap, "pmap", torch.int32)
+        assert pmap.numel() == p.numel()
+        _lib.check(self.lib.vgan_adadelta_step_packed(_ptr(p), _ptr(pmap), _ptr(g_packed), _ptr(w_packed), _ptr(sq), _ptr(acc),
+                                                      p.numel(), float(lr), float(rho), float(eps), float(weight_decay),
+                                                      float(grad_scale), self._stream()), "vgan_adadelta_step_packed")
+
+    def noise_normal(self, z, seed, step_counter, stream_id=0, cols=None, ones_col=-1):
+        """z [rows, ld]: standard normals in the first `cols` columns (default all); optional column of ones."""
+        _mat(z, "z")
+        rows, ld = z.shape[0], z.stride(0)
+        cols = z.shape[1] if cols is None else int(cols)
+        _lib.check(self.lib.vgan_noise_normal(_ptr(z), rows, cols, ld, int(ones_col), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              _ptr(step_counter), int(stream_id), self._stream()), "vgan_noise_normal")
+
+    def homogeneous_pack(self, layers, unpack=False):
+        """layers: [(W [out,in], b [out], P [>=out+1, >=in+1]) ...].  pack: P = [[W, b],[0, 1]]; unpack: (W, b) <- P.
+        One launch for all layers; the device-side pointer table is built once per distinct layer set."""
+        key = tuple((W.data_ptr(), b.data_ptr(), P.data_ptr()) for W, b, P in layers)
+        cache = self.__dict__.setdefault("_pack_tables", {})
+        if key not in cache:
+            rows = []
+            for W, b, P in layers:
+                _mat(W, "W"), _vec(b, "b"), _mat(P, "P")
+                out, kin = W.shape
+                assert b.numel() == out and P.shape[0] >= out + 1 and P.shape[1] >= kin + 1
+                rows.append([W.data_ptr(), b.data_ptr(), P.data_ptr(), out, kin, W.stride(0), P.stride(0), 0])
+            cache[key] = (torch.tensor(rows, dtype=torch.int64, device=layers[0][0].device),
+                          max((r[3] + 1) * (r[4] + 1) for r in rows))
+        desc, max_elems = cache[key]
+        _lib.check(self.lib.vgan_homogeneous_pack(_ptr(desc), desc.shape[0], int(max_elems), int(bool(unpack)), self._stream()),
+                   "vgan_homogeneous_pack")
 
     def mse(self, a, b, scale, out, accumulate=False):
         _mat(a, "a"), _mat(b, "b")

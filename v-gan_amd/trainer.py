@@ -14,14 +14,28 @@ dp = d rounded up to 4, L = latent size):
   perm [batches_per_epoch, n] int32       this epoch's shuffled indices
   Z [2n, dp]  sq [2n]                     MMD operand [X_batch ; U*X_batch] and its row norms
   Wg [nl, 2n]                             gradient weights of this rank's Y rows (never the 5x2nx2n K)
-  acts: z [n, L], h1, h2, h3, logits [nl, *];  S [nl, d];  gU [nl, dp];  dlogits, dh3, dh2, dh1
+  S [nl, d], gU [slabs, nl, dp], dlogits  mask softmax, split-K slabs of dY*X, logits gradient
+
+Generator (src/models/Generator.py:58-70 has NO activation between its Linear layers):
+  "layered"    four GEMMs forward, seven backward, intermediate activations [nl, 2L..8L] kept;
+  "collapsed"  (default) the chain in homogeneous coordinates: Wt_k = [[W_k, b_k],[0, 1]],
+               At_k = Wt_k .. Wt_1, logits = [z|1] . At_4^T; backward from M4 = dlogits^T [z|1] ([d, L+1]):
+               M_{k-1} = Wt_k^T M_k and dWt_k = M_k At_{k-1}^T.  Every product has an inner or outer dimension
+               of L+1 instead of the batch: ~0.2 GFLOP/step instead of 2.5 at d=784, same mathematics
+               (different fp32 association; parity-tested like the layered path).
 
 Data parallel (exact): rank r owns rows [r*n/G, (r+1)*n/G) of the batch.  Exchange per
 step: all-gather of the Y rows (+ their norms), all-reduce(MAX) of the packed column arg-max keys,
-all-reduce(SUM) of the four block statistics, all-reduce(SUM) of the flat gradient.  Every rank
-applies the identical Adadelta update.  The data set and the noise stream are replicated, so
-results do not depend on the number of ranks.
+all-reduce(SUM) of the four block statistics, all-reduce(SUM) of the generator gradient (the flat
+gradient when layered; only M4, 10x smaller, when collapsed).  Every rank applies the identical
+Adadelta update.  The data set and the noise stream are replicated, so results do not depend on G.
+
+Measured and rejected (MI355X, ROCm 7.2, c3): a fork/join HIP graph (XX tiles and weight-gradient GEMMs
+on side streams) replays SLOWER than the plain chain (357 vs 313 us/step): each cross-stream edge costs
+more than the overlap returns.
 """
+import os
+
 import torch
 
 ADADELTA_RHO = 0.9   # torch.optim.Adadelta defaults used by the reference (src/vgan.py:567-568)
@@ -63,18 +77,19 @@ class FlatParams:
 
 class NoKLStepEngine:
     def __init__(self, ops, generator, data, batch_size, batches_per_epoch, lr=0.007, weight_decay=0.04, penalty_weight=10.0,
-                 seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None):
+                 seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None,
+                 generator_mode=None):
         self.ops = ops
         self.dev = data.device
         self.rank, self.world, self.group = rank, world, group
         n = self.n = int(batch_size)
         if n % world != 0:
             raise ValueError(f"global batch {n} must be divisible by the number of ranks {world}")
-        self.nl = n // world
-        self.lo = rank * self.nl
+        nl = self.nl = n // world
+        self.lo = rank * nl
         self.data = data
-        self.d = d = data.shape[1]
-        self.dp = _round4(d)
+        d = self.d = data.shape[1]
+        dp = self.dp = _round4(d)
         self.nb = int(batches_per_epoch)
         self.lr, self.wd, self.pen = float(lr), float(weight_decay), float(penalty_weight)
         self.seed = int(seed)
@@ -82,35 +97,70 @@ class NoKLStepEngine:
         self.use_graph = bool(use_graph) and data.is_cuda
         self.graph = None
         self.steps_done = 0
+        self.mode = generator_mode or os.environ.get("VGAN_GENERATOR", "collapsed")
+        if self.mode not in ("collapsed", "layered"):
+            raise ValueError(f"generator_mode must be 'collapsed' or 'layered', got {self.mode!r}")
 
         lin = [m for m in generator.main if isinstance(m, torch.nn.Linear)]
         assert len(lin) == 4
-        self.L = lin[0].in_features
+        L = self.L = lin[0].in_features
+        self.widths = [L] + [m.out_features for m in lin]
         params = [q for m in lin for q in (m.weight, m.bias)]
         self.fp = FlatParams(params, self.dev)
         self.W = [self.fp.view(self.fp.flat, 2 * k) for k in range(4)]
         self.b = [self.fp.view(self.fp.flat, 2 * k + 1) for k in range(4)]
-        # weight gradients contract over the batch rows: split that contraction into slabs so the launch fills
-        # the chip, then sum the slabs (fixed order) into the flat gradient
-        self.splits = max(1, min(8, (n // world) // 128))
-        self.gslab = torch.zeros(self.splits, self.fp.total, dtype=torch.float32, device=self.dev) if self.splits > 1 else None
-        gbase = self.gslab[0] if self.splits > 1 else self.fp.grad
-        self.dW = [self.fp.view(gbase, 2 * k) for k in range(4)]
-        self.db = [self.fp.view(gbase, 2 * k + 1) for k in range(4)]
 
         f32 = dict(dtype=torch.float32, device=self.dev)
-        nl, dp = self.nl, self.dp
-        self.z_full = torch.zeros(n, self.L, **f32)
-        widths = [self.L] + [m.out_features for m in lin]
-        self.acts = [self.z_full[self.lo:self.lo + nl]] + [torch.zeros(nl, w, **f32) for w in widths[1:]]
-        self.dacts = [None] + [torch.zeros(nl, w, **f32) for w in widths[1:4]]
+        # products that contract over the batch rows are cut into row slices ("slabs", summed in fixed order)
+        # so that a launch with a small output still fills the chip
+        self.splits = max(1, min(8, nl // 128))
+        self.e = [_round4(w + 1) for w in self.widths]  # padded homogeneous widths
+        self.za = torch.zeros(n, self.e[0], **f32)       # [z | 1 | 0-pad] for ALL batch rows (noise stream is replicated)
+        self.za[:, L] = 1.0
+        self.z_own = self.za[self.lo:self.lo + nl]
+        self.logits = torch.zeros(nl, d, **f32)
+        if self.mode == "layered":
+            self.gslab = torch.zeros(self.splits, self.fp.total, **f32) if self.splits > 1 else None
+            gbase = self.gslab[0] if self.splits > 1 else self.fp.grad
+            self.dW = [self.fp.view(gbase, 2 * k) for k in range(4)]
+            self.db = [self.fp.view(gbase, 2 * k + 1) for k in range(4)]
+            self.acts = [self.z_own[:, :L]] + [torch.zeros(nl, w, **f32) for w in self.widths[1:4]] + [self.logits]
+            self.dacts = [None] + [torch.zeros(nl, w, **f32) for w in self.widths[1:4]]
+        else:
+            e = self.e
+            # packed weights Wt_k = [[W_k, b_k],[0, 1]] and packed gradients Gt_k = [dW_k | db_k] share ONE offset table, so
+            # Adadelta can read the gradient of a flat element and write its updated value through a single index map
+            poff = [0]
+            for k in range(1, 5):
+                poff.append(poff[-1] + e[k] * e[k - 1])
+            self.Wt_all = torch.zeros(poff[-1], **f32)
+            self.Gt_all = torch.zeros(poff[-1], **f32)
+            self.Wt = [None] + [self.Wt_all[poff[k - 1]:poff[k]].view(e[k], e[k - 1]) for k in range(1, 5)]
+            self.Gt = [None] + [self.Gt_all[poff[k - 1]:poff[k]].view(e[k], e[k - 1]) for k in range(1, 5)]
+            self.At = [None, self.Wt[1]] + [torch.zeros(e[k], e[0], **f32) for k in range(2, 5)]  # Wt_k .. Wt_1 (At_1 = Wt_1)
+            self.M = [None, self.Gt[1]] + [torch.zeros(e[k], e[0], **f32) for k in range(2, 5)]   # M_1 IS Gt_1 (At_0 = I)
+            pmap = torch.full((self.fp.total,), -1, dtype=torch.int32)
+            for k in range(1, 5):
+                wk, wk1 = self.widths[k], self.widths[k - 1]
+                r = torch.arange(wk, dtype=torch.int32)[:, None] * e[k - 1]
+                ow, ob = self.fp.offsets[2 * (k - 1)], self.fp.offsets[2 * (k - 1) + 1]
+                pmap[ow:ow + wk * wk1] = (poff[k - 1] + r + torch.arange(wk1, dtype=torch.int32)[None, :]).reshape(-1)
+                pmap[ob:ob + wk] = (poff[k - 1] + r + wk1).reshape(-1)
+            self.pmap = pmap.to(self.dev)
+            # row slices of the three products whose contraction is long: M4 (batch rows), M3 (d), M2 (8L)
+            self.msplit = {4: self.splits, 3: 4 if e[4] >= 512 else 1, 2: 2 if e[3] >= 256 else 1, 1: 1}
+            self.Mslab = {k: (torch.zeros(s, e[k] * e[0], **f32) if s > 1 else None) for k, s in self.msplit.items()}
+            self.pack_layers = [(self.W[k - 1], self.b[k - 1], self.Wt[k]) for k in range(1, 5)]
+            self.unpack_layers = [(self.fp.view(self.fp.grad, 2 * (k - 1)), self.fp.view(self.fp.grad, 2 * (k - 1) + 1), self.Gt[k])
+                                  for k in range(1, 5)]
+            ops.homogeneous_pack(self.pack_layers, unpack=False)  # once; afterwards Adadelta keeps Wt current
+
         self.S = torch.zeros(nl, d, **f32)
         self.Z = torch.zeros(2 * n, dp, **f32)
         self.sqn = torch.zeros(2 * n, **f32)
         self.Wg = torch.zeros(nl, 2 * n, **f32)
         # the backward GEMM contracts over the 2n rows of Z: sliced so that every SIMD holds several waves; the
         # partial slabs are summed by the mask-backward kernel
-        import os
         self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", "2")))
         self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
         self.gU = self.gU_slabs[0]
@@ -118,21 +168,6 @@ class NoKLStepEngine:
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev)
         self.partial = torch.zeros(self.tiles.shape[0], 4, **f32)
-        # The XX block only feeds the loss value, never the gradient: on one GPU it is launched from its own tile
-        # table on a side stream so that it fills the CUs the gradient path (XY/YY tiles -> backward GEMM) leaves idle.
-        # Measured on MI355X / ROCm 7.2 (c3): the fork/join graph is SLOWER than the plain chain (357 vs 313 us/step) --
-        # every cross-stream edge of a replayed HIP graph costs more than the overlap returns -- so it is opt-in.
-        import os
-        self.concurrent = bool(data.is_cuda and world == 1 and os.environ.get("VGAN_CONCURRENT", "0") not in ("0", ""))
-        self.concurrent_dw = os.environ.get("VGAN_CONCURRENT", "0") in ("1", "dw")
-        self.concurrent_xx = os.environ.get("VGAN_CONCURRENT", "0") in ("1", "xx")
-        if self.concurrent:
-            slot = (self.tiles[:, 4] & 3)
-            self.tiles_xx = self.tiles[slot == 0].contiguous()
-            self.tiles_g = self.tiles[slot != 0].contiguous()
-            self.partial_xx = torch.zeros(self.tiles_xx.shape[0], 4, **f32)
-            self.partial_g = torch.zeros(self.tiles_g.shape[0], 4, **f32)
-            self.side = [torch.cuda.Stream(device=self.dev) for _ in range(2)]
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
         self.has_bw = False
@@ -153,8 +188,8 @@ class NoKLStepEngine:
         self.has_bw = True
 
     def set_noise(self, z):
-        """Host-provided noise for the next step (parity runs: the reference draws it on the CPU)."""
-        self.z_full.copy_(z.to(dtype=torch.float32), non_blocking=True)
+        """Host-provided noise [n, L] for the next step (parity runs: the reference draws it on the CPU)."""
+        self.za[:, :self.L].copy_(z.to(dtype=torch.float32), non_blocking=True)
 
     def epoch_loss(self):
         """Mean loss of the steps since the last call (one host sync), as the reference's
@@ -162,6 +197,75 @@ class NoKLStepEngine:
         v = float(self.loss_accum.item())
         self.loss_accum.zero_()
         return v
+
+    def grad_view(self, k):
+        """Gradient of parameter tensor k as of the last step (sums split-K slabs that Adadelta consumed directly)."""
+        if self.mode == "collapsed":
+            self.ops.homogeneous_pack(self.unpack_layers, unpack=True)  # packed gradients -> flat layout (inspection only)
+        elif self.world == 1 and self.splits > 1:
+            return sum(self.fp.view(self.gslab[sl], k) for sl in range(self.splits))
+        return self.fp.view(self.fp.grad, k)
+
+    # ---- generator -----------------------------------------------------------------------------------
+    def _generator_forward(self):
+        ops = self.ops
+        if self.mode == "layered":
+            for k in range(4):
+                ops.linear_forward(self.acts[k], self.W[k], self.b[k], self.acts[k + 1])
+            return
+        for k in (2, 3, 4):  # At_k = Wt_k . At_{k-1}   (Wt is kept current by the optimiser)
+            ops.linear_backward_input(self.Wt[k], self.At[k - 1], self.At[k])
+        ops.linear_forward(self.z_own, self.At[4][:self.d], None, self.logits)
+
+    def _m_operand(self, k, reduced):
+        """M_k as a GEMM operand: (tensor, nslabs, slab_stride).  The slabs are reduced by their own launch: letting the
+        consumers' staging loads sum them (the C ABI supports it) was measured 3x SLOWER at 8 slabs (20.9 vs 7.5 us per
+        product: every K tile re-reads all slabs), so `reduced=False` is only honoured for two slabs."""
+        if self.msplit[k] == 1:
+            return self.M[k], 1, 0
+        if reduced or self.msplit[k] > 2:
+            self.ops.reduce_slabs(self.Mslab[k], self.e[k] * self.e[0], self.msplit[k], self.M[k].view(-1))
+            return self.M[k], 1, 0
+        return self.Mslab[k][0].view(self.e[k], self.e[0]), self.msplit[k], self.e[k] * self.e[0]
+
+    def _generator_backward_update(self, dist):
+        """dlogits -> parameter gradients -> (all-reduce) -> Adadelta."""
+        ops = self.ops
+        adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=1.0)
+        if self.mode == "layered":
+            g = self.dlogits
+            for k in (3, 2, 1, 0):
+                ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
+                if k:
+                    ops.linear_backward_input(g, self.W[k], self.dacts[k])
+                    g = self.dacts[k]
+            if dist:
+                if self.splits > 1:
+                    ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
+                dist.all_reduce(self.fp.grad, group=self.group)
+                ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, **adadelta)
+            elif self.splits > 1:  # single rank: Adadelta sums the slabs itself
+                ops.adadelta_step(self.fp.flat, self.gslab[0], self.fp.sq, self.fp.acc, nslabs=self.splits, slab_stride=self.fp.total,
+                                  **adadelta)
+            else:
+                ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, **adadelta)
+            return
+        e, d = self.e, self.d
+        # M4[:d] = dlogits^T . [z|1]   (rows >= d stay zero: the homogeneous output coordinate carries no gradient)
+        tgt = self.Mslab[4][0].view(e[4], e[0]) if self.msplit[4] > 1 else self.M[4]
+        ops.linear_backward_params(self.dlogits, self.z_own, tgt[:d], None, self.msplit[4], e[4] * e[0])
+        mop = {4: self._m_operand(4, reduced=dist is not None)}
+        if dist:
+            dist.all_reduce(self.M[4], group=self.group)
+        for k in (4, 3, 2):  # M_{k-1} = Wt_k^T . M_k
+            tgt = self.Mslab[k - 1][0].view(e[k - 1], e[0]) if self.msplit[k - 1] > 1 else self.M[k - 1]
+            m, ns, st = mop[k]
+            ops.linear_backward_params(self.Wt[k], m, tgt, None, self.msplit[k - 1], e[k - 1] * e[0], ns, st)
+            mop[k - 1] = self._m_operand(k - 1, reduced=False)
+        for k in (4, 3, 2):  # [dW_k | db_k] = M_k . At_{k-1}^T   (k = 1: At_0 = I, so Gt_1 is M_1 itself)
+            m, ns, st = mop[k]
+            ops.linear_forward(m, self.At[k - 1], None, self.Gt[k], ns, st)
+        ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta)
 
     # ---- the step -----------------------------------------------------------------------------------
     def _collect(self):
@@ -171,17 +275,16 @@ class NoKLStepEngine:
     def _forward(self):
         ops, n, nl, lo = self.ops, self.n, self.nl, self.lo
         if self.noise_mode == "device":
-            ops.noise_normal(self.z_full, self.seed, self.step_counter, 0)
-        for k in range(4):
-            ops.linear_forward(self.acts[k], self.W[k], self.b[k], self.acts[k + 1])
+            ops.noise_normal(self.za, self.seed, self.step_counter, 0, cols=self.L, ones_col=self.L)
+        self._generator_forward()
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
         if self.world == 1:
-            ops.mask_project_forward(self.acts[4], self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n],
+            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n],
                                      self.sqn[n:], row_offset=0, **rowsel)
         else:
             dist = self._collect()
             ops.gather_rows(self.data, self.perm, self.Z[:n], self.sqn[:n], row_offset=0, **rowsel)
-            ops.mask_project_forward(self.acts[4], self.data, self.perm, self.S, None, None, self.Z[n + lo:n + lo + nl], None,
+            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, None, self.Z[n + lo:n + lo + nl], None,
                                      self.sqn[n + lo:n + lo + nl], row_offset=lo, **rowsel)
             dist.all_gather_into_tensor(self.Z[n:], self.Z[n + lo:n + lo + nl], group=self.group)
             dist.all_gather_into_tensor(self.sqn[n:], self.sqn[n + lo:n + lo + nl], group=self.group)
@@ -215,100 +318,18 @@ class NoKLStepEngine:
             ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
         ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride)
         ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
-        g = self.dlogits
-        for k in (3, 2, 1, 0):
-            ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
-            if k:
-                ops.linear_backward_input(g, self.W[k], self.dacts[k])
-                g = self.dacts[k]
-        if dist:
-            if self.splits > 1:
-                ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
-            dist.all_reduce(self.fp.grad, group=self.group)
-            ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0)
-        elif self.splits > 1:  # single rank: Adadelta sums the slabs itself
-            ops.adadelta_step(self.fp.flat, self.gslab[0], self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0,
-                              self.splits, self.fp.total)
-        else:
-            ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0)
-
-    def grad_view(self, k):
-        """Gradient of parameter tensor k as of the last step (sums the split-K slabs if they were not reduced)."""
-        if self.world == 1 and self.splits > 1:
-            return sum(self.fp.view(self.gslab[sl], k) for sl in range(self.splits))
-        return self.fp.view(self.fp.grad, k)
-
-    def _loss_backward_update_concurrent(self):
-        """Single-GPU step tail as a fork/join graph over three streams (captured into the same HIP graph):
-             main : gram(XY,YY) -> backward GEMM -> mask backward -> dh chain -> slab reduce -> Adadelta
-             side0: column arg-max, gram(XX) -> block sums -> loss           (joins at the end of the step)
-             side1: the four weight-gradient GEMMs, each as soon as its dy exists
-        Independent kernels overlap, and the short or under-filled ones (XX tiles, dW GEMMs) run in the holes of
-        the long ones (528 Gram tiles / 208 backward tiles do not divide 256 CUs)."""
-        ops, n, d = self.ops, self.n, self.d
-        main = torch.cuda.current_stream()
-        s0, s1 = self.side
-        if self.concurrent_xx:
-            s0.wait_stream(main)
-            with torch.cuda.stream(s0):
-                ops.colmax(self.S, 0, self.colpart, self.colkey, True)
-                ev_colmax = torch.cuda.Event()
-                ev_colmax.record(s0)
-                ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles_xx, False, None, 0, self.partial_xx)
-            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles_g, False, self.Wg, n, self.partial_g)
-            ev_gram = torch.cuda.Event()
-            ev_gram.record(main)
-            with torch.cuda.stream(s0):
-                s0.wait_event(ev_gram)
-                ops.mmd_reduce(self.partial_xx, self.tiles_xx, self.stats, True)
-                ops.mmd_reduce(self.partial_g, self.tiles_g, self.stats, False)
-                ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
-            ops.mmd_backward(self.Wg, self.Z, n, n, 2 * n, self.dp, self.Z[:n], self.gU, self.bsplits, n * self.dp)
-            main.wait_event(ev_colmax)
-        else:
-            ops.colmax(self.S, 0, self.colpart, self.colkey, True)
-            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n, self.partial)
-            ops.mmd_reduce(self.partial, self.tiles, self.stats, True)
-            ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
-            ops.mmd_backward(self.Wg, self.Z, n, n, 2 * n, self.dp, self.Z[:n], self.gU, self.bsplits, n * self.dp)
-        ops.mask_backward(self.gU, self.S, self.colkey, self.pen, 0, self.dlogits, self.bsplits, n * self.dp)
-        g = self.dlogits
-        for k in (3, 2, 1, 0):
-            if self.concurrent_dw:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(s1):
-                    s1.wait_event(ev)
-                    ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
-            else:
-                ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
-            if k:
-                ops.linear_backward_input(g, self.W[k], self.dacts[k])
-                g = self.dacts[k]
-        if self.concurrent_dw:
-            main.wait_stream(s1)
-        if self.splits > 1:
-            ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
-        ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, self.lr, ADADELTA_RHO, ADADELTA_EPS, self.wd, 1.0)
-        if self.concurrent_xx:
-            main.wait_stream(s0)
+        self._generator_backward_update(dist)
 
     def _step_body(self):
         self._forward()
-        if self.concurrent:
-            self._loss_backward_update_concurrent()
-        else:
-            self._loss_backward_update()
+        self._loss_backward_update()
 
     def step(self):
         """Runs one training step asynchronously.  The first step also calibrates the bandwidth."""
         if not self.has_bw:
             self._forward()
             self._calibrate()
-            if self.concurrent:
-                self._loss_backward_update_concurrent()
-            else:
-                self._loss_backward_update()
+            self._loss_backward_update()
         elif self.use_graph:
             if self.graph is None:
                 self._capture()
@@ -327,7 +348,7 @@ class NoKLStepEngine:
 
     # ---- sampling (generate_subspaces) ---------------------------------------------------------
     def generator_logits(self, z):
-        """Generator forward on caller noise [m, L] -> logits [m, d] (fresh buffers, eager)."""
+        """Generator forward on caller noise [m, L] -> logits [m, d] (fresh buffers, eager, layer by layer)."""
         ops = self.ops
         h = z.to(device=self.dev, dtype=torch.float32).contiguous()
         for k in range(4):

@@ -366,16 +366,21 @@ class VGAN(_RunFolder):
                 acc = torch.zeros((), device=device)
                 for idx in epoch_batches(train_size, self.batch_size):
                     batch = data[idx.to(device)]
-                    batch_enc, batch_dec = detector(batch)
-                    fake_subspaces = generator(noise_tensor.normal_().to(device))
-                    projected_enc, projected_dec = detector(fake_subspaces * batch)
+                    # Reference quirk, kept because it decides every number this phase produces: src/vgan.py:308-310 wraps
+                    # the generator output in the legacy ``Variable(...)`` constructor, which DETACHES it, and then sets
+                    # requires_grad on the detached leaf.  ``batch_loss_G.backward()`` (:326) therefore never reaches the
+                    # generator's parameters, ``gen_optimizer.step()`` (:327) sees no gradients and changes nothing: in
+                    # VGAN.fit the generator keeps its N(0, 0.1) initialisation (fixture f4: genT == gen0 bit for bit) and
+                    # this phase only evaluates the loss.  The backward pass has no observable effect (the gradients it
+                    # leaves on the detector are zeroed before their next use), so it is not run here.
+                    with torch.no_grad():
+                        batch_enc, batch_dec = detector(batch)
+                        fake_subspaces = generator(noise_tensor.normal_().to(device))
+                        projected_enc, projected_dec = detector(fake_subspaces * batch)
+                        batch_loss_G = loss_function(batch_enc, projected_enc, fake_subspaces)
                     for p in detector.parameters():  # src/vgan.py:319-320: freezes the detector for good
                         p.requires_grad = False
-                    gen_optimizer.zero_grad()
-                    batch_loss_G = loss_function(batch_enc, projected_enc, fake_subspaces)
                     self.bandwidth = loss_function.bandwidth
-                    batch_loss_G.backward()
-                    gen_optimizer.step()
                     acc += batch_loss_G.detach() / batch_number
                 generator_loss = float(acc)
                 iternum_g += 1
