@@ -136,6 +136,13 @@ int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int32_t* out
 int vgan_mmd_gram(const float* Z, int ldz, const float* sq, int n, int p, const float* bw,
                   const int32_t* tiles, int ntiles, int calibrate,
                   float* Wg, int ldw, int wrow0, float* partial, vgan_stream_t stream);
+/* vgan_mmd_gram (calibrate = 0) and vgan_colmax_partial in ONE launch: the column arg-max cells run in surplus
+ * workgroups behind the Gram tiles (they are independent of each other, and the Gram grid leaves CUs idle in its
+ * tail).  Arguments as in the two separate calls; colpart has vgan_colmax_chunks(nrows)*d entries. */
+int vgan_mmd_gram_colmax(const float* Z, int ldz, const float* sq, int n, int p, const float* bw,
+                         const int32_t* tiles, int ntiles, float* Wg, int ldw, int wrow0, float* partial,
+                         const float* S, int lds, int from_softmax, int row_offset, uint64_t* colpart,
+                         int nrows, int d, vgan_stream_t stream);
 /* stats[4] (double): {Sxx, Sxy, Syy, sumL} += reduction of partial[] by tile slot (deterministic).
  * zero_first != 0 clears stats before accumulating. */
 int vgan_mmd_reduce(const float* partial, const int32_t* tiles, int ntiles, double* stats,
@@ -200,10 +207,15 @@ int vgan_noise_normal(float* z, int rows, int cols, int ld, int ones_col, uint64
 int vgan_homogeneous_pack(const int64_t* desc, int count, int max_elems, int unpack, vgan_stream_t stream);
 /* Adadelta for that chain without pack/unpack launches: the gradient of flat element i is
  * g_packed[pmap[i]] and the updated parameter is also stored to w_packed[pmap[i]] (pmap[i] < 0: layout
- * padding, skipped).  Same update rule as vgan_adadelta_step. */
+ * padding, skipped).  Same update rule as vgan_adadelta_step.
+ * next_noise != NULL: the kernel also draws the noise of the NEXT step (vgan_noise_normal with
+ * stream_id 0 and the current value of *step_counter, which the loss kernel has already advanced),
+ * saving the separate noise launch at the head of every step. */
 int vgan_adadelta_step_packed(float* p, const int32_t* pmap, const float* g_packed, float* w_packed,
                               float* sq_avg, float* acc_delta, int64_t count, float lr, float rho,
-                              float eps, float weight_decay, float grad_scale, vgan_stream_t stream);
+                              float eps, float weight_decay, float grad_scale, float* next_noise,
+                              int noise_rows, int noise_cols, int noise_ld, int noise_ones_col,
+                              uint64_t seed, const uint64_t* step_counter, vgan_stream_t stream);
 
 /* sum of squared differences: out[0] (+)= scale * sum((a-b)^2)  -- `__distance(x,y,'L2')`,
  * src/vgan.py:58-59, and its gradient  ga (+)= gscale*(a-b), gb (+)= -gscale*(a-b). */

@@ -179,6 +179,10 @@ class CpuOps:
                     wg[np.ix_(cj - wrow0, ri)] = w.T
         partial.reshape(-1, 4)[:tiles.shape[0]].copy_(torch.as_tensor(part))
 
+    def mmd_gram_colmax(self, Z, sq, n, p, bw, tiles, Wg, wrow0, partial, S, row_offset, colpart, from_softmax=True):
+        self.mmd_gram(Z, sq, n, p, bw, tiles, False, Wg, wrow0, partial)
+        self.colmax_partial(S, row_offset, colpart, from_softmax)
+
     def mmd_reduce(self, partial, tiles, stats, zero_first=True):
         st = np.zeros(4)
         p = _np(partial).reshape(-1, 4).astype(np.float64)
@@ -230,7 +234,10 @@ class CpuOps:
         sq.copy_(torch.as_tensor(sn))
         acc.copy_(torch.as_tensor(an))
 
-    def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+    def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0,
+                             next_noise=None, noise_cols=0, noise_ones_col=-1, seed=0, step_counter=None):
+        if next_noise is not None:
+            self.noise_normal(next_noise, seed, step_counter, 0, cols=noise_cols, ones_col=noise_ones_col)
         m = pmap.long()
         live = m >= 0
         g = torch.zeros_like(p)

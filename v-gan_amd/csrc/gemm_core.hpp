@@ -433,6 +433,109 @@ struct GemmTile {
     }
 };
 
+
+// ---- tall-skinny / tiny products: 32x32 tile per workgroup, the four waves split every K tile ---------------
+// A chain of small products (the collapsed generator: outputs of at most 788 x 52, contractions of 100..1024) is
+// bound by the LENGTH of the K loop of its few tiles, not by throughput.  Here the output tile is 32x32, so there are
+// 4-8x more workgroups than with 64x64 tiles, and wave w of a workgroup takes the k-groups [w*BK/32, (w+1)*BK/32) of
+// each BK-deep K tile (BK = 128: 16 MFMAs per wave per K tile, as in the big engine), so the loop is BK/32 = 4x shorter.
+// The four partial accumulators meet in LDS once at the end; wave w then owns result registers 4w..4w+3.
+template <int BK, int LA, int LB, int VEC>
+struct GemmTileKS {
+    static constexpr int T = 32;
+    static constexpr int kImgA = (LA == KC) ? T * (BK + kPad) : BK * (T + kPad);
+    static constexpr int kImgB = (LB == KC) ? T * (BK + kPad) : BK * (T + kPad);
+    static constexpr int kLdsFloats = 2 * (kImgA + kImgB);
+    static constexpr int GW = BK / 32;  // k-groups (of 8) per wave per K tile
+    static_assert(BK % 32 == 0 && kLdsFloats >= 4 * 16 * 64, "K tile / reduction scratch");
+
+    template <int LAYOUT>
+    __device__ static __forceinline__ f32x4 frag(const lds_f* img, int mn, int c, int fh) {
+        if constexpr (LAYOUT == KC) {
+            return *(const lds_f4*)(img + mn * (BK + kPad) + 8 * c + 4 * fh);
+        } else {
+            const lds_f* q = img + (8 * c + 4 * fh) * (T + kPad) + mn;
+            return f32x4{q[0], q[T + kPad], q[2 * (T + kPad)], q[3 * (T + kPad)]};
+        }
+    }
+
+    // out[rr] (rr = 0..3) = full sum for result register 4*wave + rr of this lane (see row_of / col_of).
+    __device__ static __forceinline__ void run(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb, int m0,
+                                               int n0, int M, int N, int K, float* lds_generic, float (&out)[4]) {
+        lds_f* lds = (lds_f*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int fi = lane & 31, fh = lane >> 5;
+        lds_f* const sA0 = lds;
+        lds_f* const sB0 = lds + 2 * kImgA;
+        Stager<T, BK, LA, VEC> ga;
+        Stager<T, BK, LB, VEC> gb;
+        ga.init(A, lda, m0, M, K, tid);
+        gb.init(B, ldb, n0, N, K, tid);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int nk = (K + BK - 1) / BK;
+        ga.load(0);
+        gb.load(0);
+        ga.store(sA0);
+        gb.store(sB0);
+        if (nk > 1) {
+            ga.load(BK);
+            gb.load(BK);
+        }
+        __syncthreads();
+        auto body = [&](int kt, auto store_next, auto load_next2) {
+            const int cur = kt & 1;
+            const lds_f* imgA = sA0 + cur * kImgA;
+            const lds_f* imgB = sB0 + cur * kImgB;
+            f32x4 a[GW], b[GW];
+#pragma unroll
+            for (int c = 0; c < GW; ++c) {
+                a[c] = frag<LA>(imgA, fi, wave * GW + c, fh);
+                b[c] = frag<LB>(imgB, fi, wave * GW + c, fh);
+            }
+            if constexpr (decltype(store_next)::value) {
+                ga.store(sA0 + (cur ^ 1) * kImgA);
+                gb.store(sB0 + (cur ^ 1) * kImgB);
+            }
+            if constexpr (decltype(load_next2)::value) {
+                ga.load((kt + 2) * BK);
+                gb.load((kt + 2) * BK);
+            }
+#pragma unroll
+            for (int c = 0; c < GW; ++c)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][st], b[c][st], acc, 0, 0, 0);
+            __builtin_amdgcn_iglp_opt(0);
+            __syncthreads();
+        };
+        using Tt = std::true_type;
+        using Ff = std::false_type;
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) body(kt, Tt{}, Tt{});
+        if (kt + 1 < nk) {
+            body(kt, Tt{}, Ff{});
+            ++kt;
+        }
+        body(kt, Ff{}, Ff{});
+        // cross-wave sum: red[w][r][lane]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[(wave * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            out[rr] = (lds[(0 * 16 + r) * 64 + lane] + lds[(1 * 16 + r) * 64 + lane]) +
+                      (lds[(2 * 16 + r) * 64 + lane] + lds[(3 * 16 + r) * 64 + lane]);
+        }
+    }
+    __device__ static __forceinline__ int row_of(int rr) {  // row inside the 32x32 tile of out[rr]
+        const int lane = threadIdx.x & 63, r = 4 * (threadIdx.x >> 6) + rr;
+        return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int col_of() { return threadIdx.x & 31; }
+};
+
 template <int WM, int WN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[WM][WN]) {
 #pragma unroll

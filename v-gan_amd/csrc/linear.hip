@@ -86,6 +86,46 @@ __global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_kernel(const floa
     if (do_bias && threadIdx.x < LBM && m0 + threadIdx.x < out) db[m0 + threadIdx.x] = side[threadIdx.x];
 }
 
+// ---- tall-skinny variants (GemmTileKS): used when the 64x64 grid would be a handful of long-K tiles -----------------
+constexpr int KSBK = 128;
+template <int VEC>
+__global__ __launch_bounds__(kBlock, 2) void linear_bwd_input_ks_kernel(const float* __restrict__ dy, int lddy,
+                                                                       const float* __restrict__ W, int ldw, float* __restrict__ dx,
+                                                                       int lddx, int n, int in, int out) {
+    using G = GemmTileKS<KSBK, KC, MC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float o[4];
+    G::run(dy, lddy, W, ldw, m0, n0, n, in, out, lds, o);
+    const int col = n0 + G::col_of();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = m0 + G::row_of(rr);
+        if (row < n && col < in) dx[(long)row * lddx + col] = o[rr];
+    }
+}
+template <int VEC>
+__global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_ks_kernel(const float* __restrict__ dy, int lddy,
+                                                                        const float* __restrict__ x, int ldx, float* __restrict__ dW,
+                                                                        int lddw, int n, int in, int out) {
+    using G = GemmTileKS<KSBK, MC, MC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float o[4];
+    G::run(dy, lddy, x, ldx, m0, n0, out, in, n, lds, o);
+    const int col = n0 + G::col_of();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = m0 + G::row_of(rr);
+        if (row < out && col < in) dW[(long)row * lddw + col] = o[rr];
+    }
+}
+// heuristic: few 64x64 tiles and a long contraction -> the K loop of a tile is the critical path
+static inline bool use_ks(int rows, int cols, int k) {
+    const long tiles64 = (long)((rows + 63) / 64) * ((cols + 63) / 64);
+    return tiles64 <= 32 && k >= 128;
+}
+
 static inline dim3 grid_for(int rows, int cols) { return dim3((cols + LBN - 1) / LBN, (rows + LBM - 1) / LBM, 1); }
 
 }  // namespace vgan
@@ -111,7 +151,13 @@ extern "C" int vgan_linear_backward_input(const float* dy, int lddy, const float
     VGAN_CHECK_ARG(dy && W && dx && n > 0 && in > 0 && out > 0 && lddy >= out && ldw >= in && lddx >= in);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldw % 4 == 0) && aligned16(dy) && aligned16(W);
-    if (vec)
+    if (use_ks(n, in, out)) {
+        dim3 g((in + 31) / 32, (n + 31) / 32);
+        if (vec)
+            hipLaunchKernelGGL(linear_bwd_input_ks_kernel<4>, g, dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
+        else
+            hipLaunchKernelGGL(linear_bwd_input_ks_kernel<1>, g, dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
+    } else if (vec)
         hipLaunchKernelGGL(linear_bwd_input_kernel<4>, grid_for(n, in), dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
     else
         hipLaunchKernelGGL(linear_bwd_input_kernel<1>, grid_for(n, in), dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
@@ -135,6 +181,15 @@ extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const floa
     grid.z = splits;  // slices beyond nz see klen <= 0 and write zeros, so the reducer may always sum `splits` slabs
     (void)nz;
     const long xs = (long)x_slab_stride;
+    if (splits == 1 && x_nslabs == 1 && db == nullptr && use_ks(out, in, n)) {  // tall-skinny: no slabs needed at all
+        dim3 g((in + 31) / 32, (out + 31) / 32);
+        if (vec)
+            hipLaunchKernelGGL(linear_bwd_params_ks_kernel<4>, g, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);
+        else
+            hipLaunchKernelGGL(linear_bwd_params_ks_kernel<1>, g, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);
+        VGAN_CHECK_LAUNCH();
+        return VGAN_OK;
+    }
 #define VGAN_BWP(V, S) hipLaunchKernelGGL((linear_bwd_params_kernel<V, S>), grid, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, db, n, in, out, kchunk, (long)slab_stride, x_nslabs, xs)
     if (x_nslabs > 1) { if (vec) VGAN_BWP(4, true); else VGAN_BWP(1, true); }
     else { if (vec) VGAN_BWP(4, false); else VGAN_BWP(1, false); }

@@ -27,14 +27,28 @@ constexpr int GBK = 32;  // 128-byte row segments per staging load (one full L2 
 // CALIB: only sum of L (first-call bandwidth).  Otherwise: sum of K = t + t^2 + t^4 + t^8 + t^16 with
 // t = exp(-L / (4 bw)), i.e. sum_k exp(-L / (bw m_k)), m = {4, 2, 1, .5, .25}, and (optionally) the
 // gradient weights Wg = sgn * (2/n^2) * dK/dL with dK/dL = -(1/bw) (t/4 + t^2/2 + t^4 + 2 t^8 + 4 t^16).
+// Column arg-max job that may ride in the Gram launch: workgroups with blockIdx.x >= ntiles each do one (64-column,
+// 64-row-chunk) cell of it.  It is independent of the Gram, tiny, and the Gram grid (528 tiles at n = 1024) leaves most
+// CUs idle during its last third, so this removes a launch from the step's critical path for free.
+struct ColmaxJob {
+    const float* S;
+    unsigned long long* part;
+    int lds, row_offset, n, d, from_softmax, nbx;  // nbx = ceil(d / 64); job is empty when S == nullptr
+};
+
 template <int VEC, bool CALIB>
 __global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ sq,
                                                             int n, int p, const float* __restrict__ bw_ptr,
-                                                            const TileDesc* __restrict__ tiles, float* __restrict__ Wg, int ldw,
-                                                            int wrow0, float* __restrict__ partial) {
+                                                            const TileDesc* __restrict__ tiles, int ntiles, float* __restrict__ Wg,
+                                                            int ldw, int wrow0, float* __restrict__ partial, ColmaxJob cj) {
     using G = GemmTile<GT, GT, GBK, KC, KC, VEC>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float red[8];
+    if ((int)blockIdx.x >= ntiles) {  // block-uniform
+        const int cb = blockIdx.x - ntiles;
+        colmax_partial_body(cj.S, cj.lds, cj.row_offset, cj.part, cj.n, cj.d, cj.from_softmax, cb % cj.nbx, cb / cj.nbx);
+        return;
+    }
     const TileDesc td = tiles[blockIdx.x];
     f32x16 acc[1][1];
     zero_acc(acc);
@@ -371,29 +385,45 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
     return count;
 }
 
+static int launch_gram(const float* Z, int ldz, const float* sq, int n, int p, const float* bw, const int32_t* tiles, int ntiles,
+                       int calibrate, float* Wg, int ldw, int wrow0, float* partial, const ColmaxJob& cj, int extra_blocks,
+                       vgan_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const TileDesc* td = reinterpret_cast<const TileDesc*>(tiles);
+    const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
+    dim3 grid(ntiles + extra_blocks), block(kBlock);
+    if (calibrate) {
+        if (vec)
+            hipLaunchKernelGGL((mmd_gram_kernel<4, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+        else
+            hipLaunchKernelGGL((mmd_gram_kernel<1, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((mmd_gram_kernel<4, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+        else
+            hipLaunchKernelGGL((mmd_gram_kernel<1, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+    }
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
 extern "C" int vgan_mmd_gram(const float* Z, int ldz, const float* sq, int n, int p, const float* bw, const int32_t* tiles,
                              int ntiles, int calibrate, float* Wg, int ldw, int wrow0, float* partial, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Z && sq && tiles && partial && n > 0 && p > 0 && ntiles > 0 && ldz >= p);
     VGAN_CHECK_ARG(calibrate || bw);
     VGAN_CHECK_ARG((reinterpret_cast<uintptr_t>(partial) & 15) == 0);
-    hipStream_t s = (hipStream_t)stream;
-    const TileDesc* td = reinterpret_cast<const TileDesc*>(tiles);
-    const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
-    dim3 grid(ntiles), block(kBlock);
-    static const int dyn_lds = getenv("VGAN_GRAM_DYNLDS") ? atoi(getenv("VGAN_GRAM_DYNLDS")) : 0;  // occupancy experiment knob
-    if (calibrate) {
-        if (vec)
-            hipLaunchKernelGGL((mmd_gram_kernel<4, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
-        else
-            hipLaunchKernelGGL((mmd_gram_kernel<1, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
-    } else {
-        if (vec)
-            hipLaunchKernelGGL((mmd_gram_kernel<4, false>), grid, block, dyn_lds, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
-        else
-            hipLaunchKernelGGL((mmd_gram_kernel<1, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, Wg, ldw, wrow0, partial);
-    }
-    VGAN_CHECK_LAUNCH();
-    return VGAN_OK;
+    return launch_gram(Z, ldz, sq, n, p, bw, tiles, ntiles, calibrate, Wg, ldw, wrow0, partial, ColmaxJob{}, 0, stream);
+}
+
+extern "C" int vgan_mmd_gram_colmax(const float* Z, int ldz, const float* sq, int n, int p, const float* bw, const int32_t* tiles,
+                                    int ntiles, float* Wg, int ldw, int wrow0, float* partial, const float* S, int lds,
+                                    int from_softmax, int row_offset, uint64_t* colpart, int nrows, int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(Z && sq && tiles && partial && bw && n > 0 && p > 0 && ntiles > 0 && ldz >= p);
+    VGAN_CHECK_ARG(S && colpart && nrows > 0 && d > 0 && lds >= d);
+    VGAN_CHECK_ARG((reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+    ColmaxJob cj{S, reinterpret_cast<unsigned long long*>(colpart), lds, row_offset, nrows, d, from_softmax, (d + 63) / 64};
+    const int extra = cj.nbx * ((nrows + kColChunkRows - 1) / kColChunkRows);
+    return launch_gram(Z, ldz, sq, n, p, bw, tiles, ntiles, 0, Wg, ldw, wrow0, partial, cj, extra, stream);
 }
 
 extern "C" int vgan_mmd_reduce(const float* partial, const int32_t* tiles, int ntiles, double* stats, int zero_first,

@@ -48,26 +48,6 @@ __global__ __launch_bounds__(kBlock) void adadelta_kernel(float* __restrict__ p,
     }
 }
 
-// Adadelta for the collapsed generator chain: the gradient of flat element i is read from the packed (homogeneous)
-// gradient image at pmap[i], and the updated parameter is ALSO written to the packed weight image at the same offset,
-// so neither an unpack launch before nor a pack launch after the optimiser is needed.  pmap[i] < 0: layout padding.
-__global__ __launch_bounds__(kBlock) void adadelta_packed_kernel(float* __restrict__ p, const int* __restrict__ pmap,
-                                                                const float* __restrict__ gpacked, float* __restrict__ wpacked,
-                                                                float* __restrict__ sq, float* __restrict__ acc, long count, float lr,
-                                                                float rho, float eps, float wd, float gs) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += stride) {
-        const int m = pmap[q];
-        if (m < 0) continue;
-        float pv = p[q], v = sq[q], a = acc[q];
-        adadelta_one(pv, gpacked[m], v, a, lr, rho, eps, wd, gs);
-        p[q] = pv;
-        sq[q] = v;
-        acc[q] = a;
-        wpacked[m] = pv;
-    }
-}
-
 // dst[i] = sum_s src[s*slab_stride + i], s ascending (fixed order)
 __global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const float* __restrict__ src, long slab_stride, int nslabs,
                                                              float* __restrict__ dst, long count, int vec) {
@@ -112,9 +92,9 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
 }
 __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
 
-__global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict__ z, int rows, int cols, int ld, int ones_col,
-                                                             unsigned long long seed, const unsigned long long* __restrict__ step_counter,
-                                                             unsigned long long stream_id) {
+__device__ __forceinline__ void noise_normal_body(float* __restrict__ z, int rows, int cols, int ld, int ones_col,
+                                                  unsigned long long seed, const unsigned long long* __restrict__ step_counter,
+                                                  unsigned long long stream_id) {
     const unsigned long long step = step_counter ? step_counter[0] : 0ull;
     const long count = (long)rows * cols;
     const long nq = (count + 3) >> 2;
@@ -138,6 +118,37 @@ __global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict_
     }
     if (ones_col >= 0)  // homogeneous coordinate [z | 1] of the collapsed generator chain
         for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) z[r * ld + ones_col] = 1.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict__ z, int rows, int cols, int ld, int ones_col,
+                                                             unsigned long long seed, const unsigned long long* __restrict__ step_counter,
+                                                             unsigned long long stream_id) {
+    noise_normal_body(z, rows, cols, ld, ones_col, seed, step_counter, stream_id);
+}
+
+// Adadelta for the collapsed generator chain: the gradient of flat element i is read from the packed (homogeneous)
+// gradient image at pmap[i], and the updated parameter is ALSO written to the packed weight image at the same offset,
+// so neither an unpack launch before nor a pack launch after the optimiser is needed.  pmap[i] < 0: layout padding.
+__global__ __launch_bounds__(kBlock) void adadelta_packed_kernel(float* __restrict__ p, const int* __restrict__ pmap,
+                                                                const float* __restrict__ gpacked, float* __restrict__ wpacked,
+                                                                float* __restrict__ sq, float* __restrict__ acc, long count, float lr,
+                                                                float rho, float eps, float wd, float gs, float* __restrict__ z,
+                                                                int zrows, int zcols, int zld, int zones, unsigned long long seed,
+                                                                const unsigned long long* __restrict__ step_counter) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += stride) {
+        const int m = pmap[q];
+        if (m < 0) continue;
+        float pv = p[q], v = sq[q], a = acc[q];
+        adadelta_one(pv, gpacked[m], v, a, lr, rho, eps, wd, gs);
+        p[q] = pv;
+        sq[q] = v;
+        acc[q] = a;
+        wpacked[m] = pv;
+    }
+    // The optimiser is the last kernel of a step and the noise draw the first of the next one: the draw for the NEXT
+    // step (the step counter was already advanced by the loss kernel) rides along here instead of costing a launch.
+    if (z != nullptr) noise_normal_body(z, zrows, zcols, zld, zones, seed, step_counter, 0ull);
 }
 
 // Homogeneous packing of Linear layers: Wt = [[W, b], [0, 1]] (zero padded to multiples of 4), so that a chain of
@@ -205,10 +216,13 @@ extern "C" int vgan_adadelta_step(float* p, const float* g, int nslabs, int64_t 
 
 extern "C" int vgan_adadelta_step_packed(float* p, const int32_t* pmap, const float* g_packed, float* w_packed, float* sq_avg,
                                          float* acc_delta, int64_t count, float lr, float rho, float eps, float weight_decay,
-                                         float grad_scale, vgan_stream_t stream) {
+                                         float grad_scale, float* next_noise, int noise_rows, int noise_cols, int noise_ld,
+                                         int noise_ones_col, uint64_t seed, const uint64_t* step_counter, vgan_stream_t stream) {
     VGAN_CHECK_ARG(p && pmap && g_packed && w_packed && sq_avg && acc_delta && count > 0);
+    VGAN_CHECK_ARG(next_noise == nullptr || (noise_rows > 0 && noise_cols > 0 && noise_ld >= noise_cols && noise_ones_col < noise_ld));
     hipLaunchKernelGGL(adadelta_packed_kernel, dim3(stream_grid(count)), dim3(kBlock), 0, (hipStream_t)stream, p, pmap, g_packed, w_packed,
-                       sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale);
+                       sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale, next_noise, noise_rows, noise_cols,
+                       noise_ld, noise_ones_col, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step_counter));
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

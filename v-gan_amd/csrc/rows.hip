@@ -210,31 +210,10 @@ __global__ __launch_bounds__(kBlock) void mask_backward_kernel(const float* __re
     }
 }
 
-// column arg-max of U = (S < tau ? S : 1) over a chunk of rows: grid (ceil(d/64), chunks)
-constexpr int kColChunkRows = 64;
+// column arg-max of U = (S < tau ? S : 1) over a chunk of rows: grid (ceil(d/64), chunks); body in vgan_common.hpp
 __global__ __launch_bounds__(kBlock) void colmax_partial_kernel(const float* __restrict__ S, int lds, int row_offset,
                                                                unsigned long long* __restrict__ part, int n, int d, int from_softmax) {
-    __shared__ unsigned long long red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * kColChunkRows;
-    const float tau = from_softmax ? 1.0f / (float)d : INFINITY;  // U given directly: no threshold
-    unsigned long long best = 0ull;
-    if (j < d) {
-        for (int r = r0 + wave; r < min(r0 + kColChunkRows, n); r += 4) {
-            const float sv = S[(long)r * lds + j];
-            const unsigned long long k = colkey_pack(sv < tau ? sv : 1.0f, (unsigned)(row_offset + r));
-            best = k > best ? k : best;
-        }
-    }
-    red[wave][lane] = best;
-    __syncthreads();
-    if (wave == 0 && j < d) {
-        unsigned long long b = red[0][lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) b = red[w][lane] > b ? red[w][lane] : b;
-        part[(long)blockIdx.y * d + j] = b;
-    }
+    colmax_partial_body(S, lds, row_offset, part, n, d, from_softmax, blockIdx.x, blockIdx.y);
 }
 __global__ void colmax_final_kernel(const unsigned long long* __restrict__ part, int chunks, unsigned long long* __restrict__ colkey,
                                     int d) {

@@ -63,6 +63,35 @@ __device__ __forceinline__ unsigned long long colkey_pack(float u, unsigned row)
 __device__ __forceinline__ float colkey_value(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
 __device__ __forceinline__ unsigned colkey_row(unsigned long long k) { return 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull); }
 
+// Column arg-max of U over one chunk of kColChunkRows rows for 64 columns (block bx covers columns 64*bx.., chunk by).
+// Shared by the stand-alone kernel (rows.hip) and by the Gram launch, which runs it in surplus workgroups.
+constexpr int kColChunkRows = 64;
+__device__ __forceinline__ void colmax_partial_body(const float* __restrict__ S, int lds, int row_offset,
+                                                    unsigned long long* __restrict__ part, int n, int d, int from_softmax, int bx,
+                                                    int by) {
+    __shared__ unsigned long long colmax_red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = bx * 64 + lane;
+    const int r0 = by * kColChunkRows;
+    const float tau = from_softmax ? 1.0f / (float)d : INFINITY;  // U given directly: no threshold
+    unsigned long long best = 0ull;
+    if (j < d) {
+        for (int r = r0 + wave; r < min(r0 + kColChunkRows, n); r += 4) {
+            const float sv = S[(long)r * lds + j];
+            const unsigned long long k = colkey_pack(sv < tau ? sv : 1.0f, (unsigned)(row_offset + r));
+            best = k > best ? k : best;
+        }
+    }
+    colmax_red[wave][lane] = best;
+    __syncthreads();
+    if (wave == 0 && j < d) {
+        unsigned long long b = colmax_red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) b = colmax_red[w][lane] > b ? colmax_red[w][lane] : b;
+        part[(long)by * d + j] = b;
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace vgan

@@ -164,6 +164,18 @@ class HipOps:
                                           int(bool(calibrate)), _ptr(Wg), ldw, int(wrow0), _ptr(partial), self._stream()),
                    "vgan_mmd_gram")
 
+    def mmd_gram_colmax(self, Z, sq, n, p, bw, tiles, Wg, wrow0, partial, S, row_offset, colpart, from_softmax=True):
+        """mmd_gram (no calibration) + colmax_partial(S) in one launch."""
+        _mat(Z, "Z"), _mat(S, "S")
+        ntiles = tiles.shape[0]
+        nrows, d = S.shape
+        assert partial.numel() >= 4 * ntiles and colpart.dtype == torch.int64 and colpart.numel() >= self.colmax_chunks(nrows) * d
+        ldw = Wg.stride(0) if Wg is not None else 0
+        _lib.check(self.lib.vgan_mmd_gram_colmax(_ptr(Z), Z.stride(0), _ptr(sq), int(n), int(p), _ptr(bw), _ptr(tiles), ntiles,
+                                                 _ptr(Wg), ldw, int(wrow0), _ptr(partial), _ptr(S), S.stride(0),
+                                                 int(bool(from_softmax)), int(row_offset), _ptr(colpart), nrows, d, self._stream()),
+                   "vgan_mmd_gram_colmax")
+
     def mmd_reduce(self, partial, tiles, stats, zero_first=True):
         assert stats.dtype == torch.float64 and stats.numel() >= 4
         _lib.check(self.lib.vgan_mmd_reduce(_ptr(partial), _ptr(tiles), tiles.shape[0], _ptr(stats), int(bool(zero_first)),
@@ -193,14 +205,19 @@ class HipOps:
                                                float(lr), float(rho), float(eps),
                                                float(weight_decay), float(grad_scale), self._stream()), "vgan_adadelta_step")
 
-    def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+    def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0,
+                             next_noise=None, noise_cols=0, noise_ones_col=-1, seed=0, step_counter=None):
+        """next_noise [rows, ld]: also draw the next step's noise (first `noise_cols` columns, optional ones column)."""
         for t, nm in ((p, "p"), (sq, "sq"), (acc, "acc"), (g_packed, "g_packed"), (w_packed, "w_packed")):
             _vec(t, nm)
         _vec(pmap, "pmap", torch.int32)
         assert pmap.numel() == p.numel()
+        zr, zld = (next_noise.shape[0], next_noise.stride(0)) if next_noise is not None else (0, 0)
         _lib.check(self.lib.vgan_adadelta_step_packed(_ptr(p), _ptr(pmap), _ptr(g_packed), _ptr(w_packed), _ptr(sq), _ptr(acc),
                                                       p.numel(), float(lr), float(rho), float(eps), float(weight_decay),
-                                                      float(grad_scale), self._stream()), "vgan_adadelta_step_packed")
+                                                      float(grad_scale), _ptr(next_noise), zr, int(noise_cols), zld,
+                                                      int(noise_ones_col), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(step_counter),
+                                                      self._stream()), "vgan_adadelta_step_packed")
 
     def noise_normal(self, z, seed, step_counter, stream_id=0, cols=None, ones_col=-1):
         """z [rows, ld]: standard normals in the first `cols` columns (default all); optional column of ones."""

@@ -147,8 +147,10 @@ class NoKLStepEngine:
                 pmap[ow:ow + wk * wk1] = (poff[k - 1] + r + torch.arange(wk1, dtype=torch.int32)[None, :]).reshape(-1)
                 pmap[ob:ob + wk] = (poff[k - 1] + r + wk1).reshape(-1)
             self.pmap = pmap.to(self.dev)
-            # row slices of the three products whose contraction is long: M4 (batch rows), M3 (d), M2 (8L)
-            self.msplit = {4: self.splits, 3: 4 if e[4] >= 512 else 1, 2: 2 if e[3] >= 256 else 1, 1: 1}
+            # The M products have long contractions (batch rows, d, 8L) and tiny outputs; the library runs them on its
+            # tall-skinny kernel (32x32 tiles, K split across the waves of a workgroup), so no row slabs are needed.
+            # (Slabs + a reduction launch, or slab-summing staging loads, were both measured slower.)
+            self.msplit = {4: 1, 3: 1, 2: 1, 1: 1}
             self.Mslab = {k: (torch.zeros(s, e[k] * e[0], **f32) if s > 1 else None) for k, s in self.msplit.items()}
             self.pack_layers = [(self.W[k - 1], self.b[k - 1], self.Wt[k]) for k in range(1, 5)]
             self.unpack_layers = [(self.fp.view(self.fp.grad, 2 * (k - 1)), self.fp.view(self.fp.grad, 2 * (k - 1) + 1), self.Gt[k])
@@ -265,7 +267,9 @@ class NoKLStepEngine:
         for k in (4, 3, 2):  # [dW_k | db_k] = M_k . At_{k-1}^T   (k = 1: At_0 = I, so Gt_1 is M_1 itself)
             m, ns, st = mop[k]
             ops.linear_forward(m, self.At[k - 1], None, self.Gt[k], ns, st)
-        ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta)
+        fused_noise = dict(next_noise=self.za, noise_cols=self.L, noise_ones_col=self.L, seed=self.seed,
+                           step_counter=self.step_counter) if self.noise_mode == "device" else {}
+        ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
 
     # ---- the step -----------------------------------------------------------------------------------
     def _collect(self):
@@ -274,7 +278,8 @@ class NoKLStepEngine:
 
     def _forward(self):
         ops, n, nl, lo = self.ops, self.n, self.nl, self.lo
-        if self.noise_mode == "device":
+        if self.noise_mode == "device" and (self.mode == "layered" or self.steps_done == 0):
+            # collapsed mode: every later draw rides in the previous step's optimiser launch (same Philox stream)
             ops.noise_normal(self.za, self.seed, self.step_counter, 0, cols=self.L, ones_col=self.L)
         self._generator_forward()
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
@@ -305,8 +310,8 @@ class NoKLStepEngine:
         dist = self._collect() if self.world > 1 else None
         gstride = nl * self.dp
         if dist is None:
-            ops.colmax_partial(self.S, lo, self.colpart, True)
-            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
+            ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, lo,
+                                self.colpart, True)
             ops.mmd_finalize(self.partial, self.tiles, self.colpart, ops.colmax_chunks(nl), self.colkey, n, d, self.pen, self.stats,
                              self.loss, self.loss_accum, self.accum_scale, self.step_counter)
         else:
