@@ -412,3 +412,53 @@ def test_vgan_kernel_learning_fit_matches_reference_run():
     masks = model.generate_subspaces(500)
     assert (host(masks) != g["masks"]).mean() < 0.05
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
+@pytest.mark.parametrize("n,d,rows", [(500, 166, 1500), (96, 33, 300), (250, 784, 500)])
+def test_ragged_shapes_trajectory_vs_oracle(ops, n, d, rows):
+    """Default-like batch sizes that are no multiple of the 64-wide tile (the reference's default is 500), feature counts
+    that are no multiple of 4, and an epoch with a dropped remainder: 6 steps against the fp64 oracle."""
+    rng = np.random.default_rng(n + d)
+    data = (rng.normal(size=(rows, d)) * rng.uniform(0.5, 2.0, size=(1, d))).astype(np.float32)
+    params = orc.synthetic_generator_params(d, seed=3)
+    L = orc.latent_size(d)
+    nb = rows // n
+    eng, _ = make_engine(ops, params, data, n, nb=nb, graph=True)
+    ref = orc.NoKLTrainer([p.astype(np.float64) for p in params])
+    perm = np.stack([rng.permutation(rows)[:n] for _ in range(nb)])
+    eng.set_epoch_batches(torch.as_tensor(perm))
+    for t in range(6):
+        z = rng.normal(size=(n, L)).astype(np.float32)
+        eng.set_noise(torch.as_tensor(z))
+        eng.step()
+        want = ref.step(data[perm[t % nb]].astype(np.float64), z.astype(np.float64))
+        assert abs(float(eng.loss) - want["loss"]) < 1e-4, (t, float(eng.loss), want["loss"])
+    np.testing.assert_allclose(float(eng.bw), ref.bw, rtol=1e-5)
+    for i in range(8):
+        np.testing.assert_allclose(host(eng.fp.view(eng.fp.flat, i)), ref.params[i], rtol=0, atol=1e-4)
+
+
+def test_c2_fit_end_to_end_device_noise():
+    """BASELINE.json configs[1] stand-in (musk-like, d=166, batch=512): a short fit with the Philox noise feed trains
+    (loss finite, bandwidth frozen after the first step, masks well-formed, run folder written like the reference's)."""
+    import tempfile, os
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    X = orc.synthetic_dataset("c2")
+    with tempfile.TemporaryDirectory() as tmp:
+        run = os.path.join(tmp, "run")
+        model = VGAN_no_kl(batch_size=512, epochs=4, seed=11, path_to_directory=run)
+        model.verbose = False
+        model.fit(X)
+        hist = model.train_history["generator_loss"]
+        assert len(hist) == 4 and np.isfinite(hist).all()
+        assert set(os.listdir(run)) >= {"models", "params.csv", "train_history"}
+        sd = torch.load(os.path.join(run, "models", "generator_0.pt"), weights_only=True)
+        assert list(sd) == [f"main.{k}.{w}" for k in range(4) for w in ("weight", "bias")]
+        m2 = VGAN_no_kl(seed=11)
+        m2.load_models(os.path.join(run, "models", "generator_0.pt"), ndims=166)
+        assert torch.equal(m2.generate_subspaces(64), model.generate_subspaces(64))
+    u = model.generate_subspaces(100)
+    assert u.shape == (100, 166) and u.dtype == torch.bool and u.any(dim=1).all()
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Exercises the data-parallel code path (RCCL collectives on the step's stream, with and without HIP-graph capture)
+on however many GPUs the launcher provides -- including ONE (world_size 1 still issues every collective), which is
+all a single-GPU box can check.  Launch:  python -m torch.distributed.run --standalone --nproc-per-node N tools/dp_selftest.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import bench
+from vgan_amd.trainer import NoKLStepEngine
+
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+
+class ForcedDP(NoKLStepEngine):
+    """world_size 1 normally takes the single-rank shortcuts; this forces the exchange code path."""
+
+
+for graph in (False, True):
+    eng, data, params = bench.build_engine(rank, world, graph)
+    if world == 1:
+        eng.world = 2          # take the DP branches ...
+        eng._real_world = 1    # ... while the process group has one member (all-gather/all-reduce of one)
+        eng.nl, eng.lo = eng.n, 0
+    losses = []
+    for t in range(6):
+        if t % bench.EPOCH_BATCHES == 0:
+            eng.set_epoch_batches(torch.arange(bench.N_BATCH * bench.EPOCH_BATCHES).view(bench.EPOCH_BATCHES, -1))
+        eng.step()
+        losses.append(float(eng.loss))
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"graph={graph} world={world}: losses {np.round(losses, 6).tolist()} captured={eng.graph is not None}")
+dist.barrier()
+dist.destroy_process_group()
