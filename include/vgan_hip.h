@@ -205,6 +205,12 @@ int vgan_noise_normal(float* z, int rows, int cols, int ld, int ones_col, uint64
  * packed is [out+1, in+1] with row stride ldp.  unpack != 0: packed -> (W, b) (rows < out only).
  * max_elems: the largest (out+1)*(in+1) in the table (sizes the grid). */
 int vgan_homogeneous_pack(const int64_t* desc, int count, int max_elems, int unpack, vgan_stream_t stream);
+/* One backward stage of that chain in ONE launch (both products read only M_k):
+ *   Mout [ek1, e0] = Wt_k^T . M_k      (Wt_k is [ek, ek1], M_k is [ek, e0])
+ *   G    [ek, ek1] = M_k . At_{k-1}^T  (At_{k-1} is [ek1, e0])   -- the packed gradient [dW_k | db_k]. */
+int vgan_chain_backward_stage(const float* Wt, int ldwt, const float* Mk, int ldm, const float* At,
+                              int ldat, float* Mout, int ldmo, float* G, int ldg, int ek, int ek1,
+                              int e0, vgan_stream_t stream);
 /* Adadelta for that chain without pack/unpack launches: the gradient of flat element i is
  * g_packed[pmap[i]] and the updated parameter is also stored to w_packed[pmap[i]] (pmap[i] < 0: layout
  * padding, skipped).  Same update rule as vgan_adadelta_step.

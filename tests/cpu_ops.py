@@ -234,6 +234,10 @@ class CpuOps:
         sq.copy_(torch.as_tensor(sn))
         acc.copy_(torch.as_tensor(an))
 
+    def chain_backward_stage(self, Wt, Mk, At, Mout, G):
+        Mout.copy_(torch.as_tensor(_np(Wt).astype(np.float64).T @ _np(Mk).astype(np.float64)))
+        G.copy_(torch.as_tensor(_np(Mk).astype(np.float64) @ _np(At).astype(np.float64).T))
+
     def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0,
                              next_noise=None, noise_cols=0, noise_ones_col=-1, seed=0, step_counter=None):
         if next_noise is not None:

@@ -40,6 +40,7 @@ SIGNATURES = {
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_noise_normal": (_i, [_p, _i, _i, _i, _i, _u64, _p, _u64, _p]),
     "vgan_homogeneous_pack": (_i, [_p, _i, _i, _i, _p]),
+    "vgan_chain_backward_stage": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _u64, _p, _p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }

@@ -205,6 +205,17 @@ class HipOps:
                                                float(lr), float(rho), float(eps),
                                                float(weight_decay), float(grad_scale), self._stream()), "vgan_adadelta_step")
 
+    def chain_backward_stage(self, Wt, Mk, At, Mout, G):
+        """Mout = Wt^T . Mk and G = Mk . At^T in one launch (collapsed generator backward, see include/vgan_hip.h)."""
+        for t, nm in ((Wt, "Wt"), (Mk, "Mk"), (At, "At"), (Mout, "Mout"), (G, "G")):
+            _mat(t, nm)
+        ek, ek1 = Wt.shape
+        e0 = Mk.shape[1]
+        assert Mk.shape[0] == ek and At.shape == (ek1, e0) and Mout.shape == (ek1, e0) and G.shape == (ek, ek1)
+        _lib.check(self.lib.vgan_chain_backward_stage(_ptr(Wt), Wt.stride(0), _ptr(Mk), Mk.stride(0), _ptr(At), At.stride(0),
+                                                      _ptr(Mout), Mout.stride(0), _ptr(G), G.stride(0), ek, ek1, e0, self._stream()),
+                   "vgan_chain_backward_stage")
+
     def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0,
                              next_noise=None, noise_cols=0, noise_ones_col=-1, seed=0, step_counter=None):
         """next_noise [rows, ld]: also draw the next step's noise (first `noise_cols` columns, optional ones column)."""

@@ -256,17 +256,13 @@ class NoKLStepEngine:
         # M4[:d] = dlogits^T . [z|1]   (rows >= d stay zero: the homogeneous output coordinate carries no gradient)
         tgt = self.Mslab[4][0].view(e[4], e[0]) if self.msplit[4] > 1 else self.M[4]
         ops.linear_backward_params(self.dlogits, self.z_own, tgt[:d], None, self.msplit[4], e[4] * e[0])
-        mop = {4: self._m_operand(4, reduced=dist is not None)}
+        if self.msplit[4] > 1:
+            self._m_operand(4, reduced=True)
         if dist:
             dist.all_reduce(self.M[4], group=self.group)
-        for k in (4, 3, 2):  # M_{k-1} = Wt_k^T . M_k
-            tgt = self.Mslab[k - 1][0].view(e[k - 1], e[0]) if self.msplit[k - 1] > 1 else self.M[k - 1]
-            m, ns, st = mop[k]
-            ops.linear_backward_params(self.Wt[k], m, tgt, None, self.msplit[k - 1], e[k - 1] * e[0], ns, st)
-            mop[k - 1] = self._m_operand(k - 1, reduced=False)
-        for k in (4, 3, 2):  # [dW_k | db_k] = M_k . At_{k-1}^T   (k = 1: At_0 = I, so Gt_1 is M_1 itself)
-            m, ns, st = mop[k]
-            ops.linear_forward(m, self.At[k - 1], None, self.Gt[k], ns, st)
+        # stage k: M_{k-1} = Wt_k^T . M_k  and  [dW_k | db_k] = M_k . At_{k-1}^T  in one launch (k = 1: At_0 = I, Gt_1 is M_1)
+        for k in (4, 3, 2):
+            ops.chain_backward_stage(self.Wt[k], self.M[k], self.At[k - 1], self.M[k - 1], self.Gt[k])
         fused_noise = dict(next_noise=self.za, noise_cols=self.L, noise_ones_col=self.L, seed=self.seed,
                            step_counter=self.step_counter) if self.noise_mode == "device" else {}
         ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
