@@ -40,14 +40,14 @@ typedef __attribute__((address_space(3))) f32x4 lds_f4;  // ext-vector: plain as
 // which would serialise the prefetch with the MFMAs it is meant to hide under.
 // SL: the operand is given as `nslabs` partial slabs `slab_stride` elements apart (split-K output of a previous
 // product); load() sums them in ascending order, which removes a separate reduction launch.
-template <int BMN, int BK, int LAYOUT, int VEC, bool SL = false>
+template <int BMN, int BK, int LAYOUT, int VEC, bool SL = false, int NTH = kBlock>
 struct Stager;
 
-template <int BMN, int BK, bool SL>
-struct Stager<BMN, BK, KC, 4, SL> {
+template <int BMN, int BK, bool SL, int NTH>
+struct Stager<BMN, BK, KC, 4, SL, NTH> {
     int nslabs = 1;
     long slab_stride = 0;
-    static constexpr int NV = BMN * BK / 4 / kBlock;
+    static constexpr int NV = BMN * BK / 4 / NTH;
     static_assert(NV >= 1, "tile too small");
     float4 v[NV];
     const float* rowp[NV];
@@ -56,10 +56,10 @@ struct Stager<BMN, BK, KC, 4, SL> {
     int kq4, K;
     __device__ __forceinline__ void init(const float* __restrict__ p, long ld, int mn0, int MN, int K_, int tid) {
         K = K_;
-        kq4 = 4 * (tid % (BK / 4));  // kBlock % (BK/4) == 0: the same k offset for every r
+        kq4 = 4 * (tid % (BK / 4));  // NTH % (BK/4) == 0: the same k offset for every r
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            const int m = (tid + kBlock * r) / (BK / 4);
+            const int m = (tid + NTH * r) / (BK / 4);
             rowok[r] = mn0 + m < MN;
             rowp[r] = p + (long)min(mn0 + m, MN - 1) * ld;
             lofs[r] = m * (BK + kPad) + kq4;
@@ -98,17 +98,17 @@ struct Stager<BMN, BK, KC, 4, SL> {
             float t = (s[r].x + s[r].y) + (s[r].z + s[r].w);
 #pragma unroll
             for (int o = 1; o < BK / 4; o <<= 1) t += __shfl_xor(t, o, 64);
-            int f = tid + kBlock * r;
+            int f = tid + NTH * r;
             if (f % (BK / 4) == 0) out[f / (BK / 4)] = t;
         }
     }
 };
 
-template <int BMN, int BK, bool SL>
-struct Stager<BMN, BK, KC, 1, SL> {
+template <int BMN, int BK, bool SL, int NTH>
+struct Stager<BMN, BK, KC, 1, SL, NTH> {
     int nslabs = 1;
     long slab_stride = 0;
-    static constexpr int NV = BMN * BK / kBlock;
+    static constexpr int NV = BMN * BK / NTH;
     float v[NV];
     const float* rowp[NV];
     int lofs[NV];
@@ -116,10 +116,10 @@ struct Stager<BMN, BK, KC, 1, SL> {
     int kk, K;
     __device__ __forceinline__ void init(const float* __restrict__ p, long ld, int mn0, int MN, int K_, int tid) {
         K = K_;
-        kk = tid % BK;  // kBlock % BK == 0
+        kk = tid % BK;  // NTH % BK == 0
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            const int m = (tid + kBlock * r) / BK;
+            const int m = (tid + NTH * r) / BK;
             rowok[r] = mn0 + m < MN;
             rowp[r] = p + (long)min(mn0 + m, MN - 1) * ld;
             lofs[r] = m * (BK + kPad) + kk;
@@ -154,19 +154,19 @@ struct Stager<BMN, BK, KC, 1, SL> {
             float t = s[r];
 #pragma unroll
             for (int o = 1; o < BK; o <<= 1) t += __shfl_xor(t, o, 64);
-            int f = tid + kBlock * r;
+            int f = tid + NTH * r;
             if (f % BK == 0) out[f / BK] = t;
         }
     }
 };
 
-template <int BMN, int BK, bool SL>
-struct Stager<BMN, BK, MC, 4, SL> {
+template <int BMN, int BK, bool SL, int NTH>
+struct Stager<BMN, BK, MC, 4, SL, NTH> {
     int nslabs = 1;
     long slab_stride = 0;
-    static constexpr int NV = BMN * BK / 4 / kBlock;
+    static constexpr int NV = BMN * BK / 4 / NTH;
     static_assert(NV >= 1, "tile too small");
-    static_assert(kBlock % (BMN / 4) == 0, "mq must be fixed per thread");
+    static_assert(NTH % (BMN / 4) == 0, "mq must be fixed per thread");
     float4 v[NV];
     const float* colp;  // p + clamped column of this thread
     long ld;
@@ -181,7 +181,7 @@ struct Stager<BMN, BK, MC, 4, SL> {
         colp = p + min(m, MN - 4);
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            krow[r] = (tid + kBlock * r) / (BMN / 4);
+            krow[r] = (tid + NTH * r) / (BMN / 4);
             lofs[r] = krow[r] * (BMN + kPad) + 4 * (tid % (BMN / 4));
         }
     }
@@ -212,7 +212,7 @@ struct Stager<BMN, BK, MC, 4, SL> {
     }
     // every staged float4 of a thread has the same mq: fold r, then across threads via LDS
     __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* scratch, lds_f* out, int tid) {
-        constexpr int ROWS = kBlock / (BMN / 4);
+        constexpr int ROWS = NTH / (BMN / 4);
         float4 t = s[0];
 #pragma unroll
         for (int r = 1; r < NV; ++r) { t.x += s[r].x; t.y += s[r].y; t.z += s[r].z; t.w += s[r].w; }
@@ -227,12 +227,12 @@ struct Stager<BMN, BK, MC, 4, SL> {
     }
 };
 
-template <int BMN, int BK, bool SL>
-struct Stager<BMN, BK, MC, 1, SL> {
+template <int BMN, int BK, bool SL, int NTH>
+struct Stager<BMN, BK, MC, 1, SL, NTH> {
     int nslabs = 1;
     long slab_stride = 0;
-    static constexpr int NV = BMN * BK / kBlock;
-    static_assert(kBlock % BMN == 0, "m must be fixed per thread");
+    static constexpr int NV = BMN * BK / NTH;
+    static_assert(NTH % BMN == 0, "m must be fixed per thread");
     float v[NV];
     const float* colp;
     long ld;
@@ -247,7 +247,7 @@ struct Stager<BMN, BK, MC, 1, SL> {
         colp = p + min(m, MN - 1);
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            krow[r] = (tid + kBlock * r) / BMN;
+            krow[r] = (tid + NTH * r) / BMN;
             lofs[r] = krow[r] * (BMN + kPad) + tid % BMN;
         }
     }
@@ -274,7 +274,7 @@ struct Stager<BMN, BK, MC, 1, SL> {
         for (int r = 0; r < NV; ++r) s[r] += v[r];
     }
     __device__ static __forceinline__ void side_reduce(const Side (&s)[NV], lds_f* scratch, lds_f* out, int tid) {
-        constexpr int ROWS = kBlock / BMN;
+        constexpr int ROWS = NTH / BMN;
         float t = s[0];
 #pragma unroll
         for (int r = 1; r < NV; ++r) t += s[r];
@@ -291,9 +291,15 @@ struct Stager<BMN, BK, MC, 1, SL> {
 
 // ---- the tile main loop --------------------------------------------------------------------
 // SLABS bit 0: the A operand arrives as slabs, bit 1: the B operand does (see Stager).
-template <int BM, int BN, int BK, int LA, int LB, int VEC, int SLABS = 0>
+// KW = 2: 512-thread workgroups; waves 4..7 mirror waves 0..3 on the second half of every K tile (k-groups split between
+// the two wave sets) and the partial accumulators are exchanged through LDS at the end, each wave keeping 8 of its 16
+// result registers (first_reg()/num_regs()).  Same MFMA count per CU, but four waves per SIMD from two resident
+// workgroups instead of two: the staging/barrier phases of one wave hide under the MFMAs of the others.
+template <int BM, int BN, int BK, int LA, int LB, int VEC, int SLABS = 0, int KW = 1>
 struct GemmTile {
+    static constexpr int NTH = kBlock * KW;
     static constexpr int WM = BM / 64, WN = BN / 64;
+    static_assert(KW == 1 || (KW == 2 && BM == 64 && BN == 64 && (BK / 8) % 2 == 0), "K-split needs one sub-tile per wave");
     static constexpr int kImgA = (LA == KC) ? BM * (BK + kPad) : BK * (BM + kPad);  // floats per buffer
     static constexpr int kImgB = (LB == KC) ? BN * (BK + kPad) : BK * (BN + kPad);
     static constexpr int kLdsFloats = 2 * (kImgA + kImgB);
@@ -320,15 +326,16 @@ struct GemmTile {
         lds_f* lds = (lds_f*)lds_generic;
         lds_f* side_lds = (lds_f*)side_generic;
         const int tid = threadIdx.x;
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = (tid >> 6) & 3, kp = tid >> 8;  // kp: which share of each K tile (KW = 2)
         const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
         const int fi = lane & 31, fh = lane >> 5;
         lds_f* const sA0 = lds;  // buffers: A0 | A1 | B0 | B1
         lds_f* const sB0 = lds + 2 * kImgA;
+        constexpr int GC = BK / 8 / KW;  // k-groups of 8 per wave per K tile
 
-        using SG = Stager<BM, BK, LA, VEC, (SLABS & 1) != 0>;
+        using SG = Stager<BM, BK, LA, VEC, (SLABS & 1) != 0, NTH>;
         SG ga;
-        Stager<BN, BK, LB, VEC, (SLABS & 2) != 0> gb;
+        Stager<BN, BK, LB, VEC, (SLABS & 2) != 0, NTH> gb;
         ga.init(A, lda, m0, M, K, tid);
         gb.init(B, ldb, n0, N, K, tid);
         if constexpr (SLABS & 1) { ga.nslabs = nslabs; ga.slab_stride = slab_stride; }
@@ -362,13 +369,13 @@ struct GemmTile {
             const int cur = kt & 1;
             const lds_f* imgA = sA0 + cur * kImgA;
             const lds_f* imgB = sB0 + cur * kImgB;
-            f32x4 a[BK / 8][WM], b[BK / 8][WN];
+            f32x4 a[GC][WM], b[GC][WN];
 #pragma unroll
-            for (int c = 0; c < BK / 8; ++c) {
+            for (int c = 0; c < GC; ++c) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) a[c][i] = frag<LA, BM>(imgA, wm0 + i * 32 + fi, c, fh);
+                for (int i = 0; i < WM; ++i) a[c][i] = frag<LA, BM>(imgA, wm0 + i * 32 + fi, kp * GC + c, fh);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) b[c][j] = frag<LB, BN>(imgB, wn0 + j * 32 + fi, c, fh);
+                for (int j = 0; j < WN; ++j) b[c][j] = frag<LB, BN>(imgB, wn0 + j * 32 + fi, kp * GC + c, fh);
             }
 #ifndef VGAN_ABLATE_NO_LDS_STORE
             if constexpr (decltype(store_next)::value) {
@@ -384,7 +391,7 @@ struct GemmTile {
             }
 #endif
 #pragma unroll
-            for (int c = 0; c < BK / 8; ++c)
+            for (int c = 0; c < GC; ++c)
 #pragma unroll
                 for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -420,15 +427,28 @@ struct GemmTile {
             SG::side_reduce(side, lds, side_lds, tid);
             __syncthreads();
         }
+        if constexpr (KW == 2) {
+            // exchange halves: wave set kp keeps registers [8 kp, 8 kp + 8) and receives the other set's share of them
+            lds_f* xch = lds;  // [set][sub-tile][8 regs][64 lanes], staging buffers are free after the loop's last barrier
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xch[((kp * 4 + wave) * 8 + r) * 64 + lane] = acc[0][0][8 * (1 - kp) + r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[0][0][8 * kp + r] += xch[(((1 - kp) * 4 + wave) * 8 + r) * 64 + lane];
+            __syncthreads();  // the epilogue may reuse lds
+        }
     }
+    // result registers this wave owns after run(): all 16 (KW = 1) or 8 of them (KW = 2)
+    __device__ static __forceinline__ int first_reg() { return KW == 2 ? 8 * (threadIdx.x >> 8) : 0; }
+    static constexpr int kNumRegs = 16 / KW;
 
     // C/D lane map of the 32x32 MFMA: reg r of lane l is (row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31).
     __device__ static __forceinline__ int sub_row(int wm, int r) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
         return (wave >> 1) * (BM / 2) + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     }
     __device__ static __forceinline__ int sub_col(int wn) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
         return (wave & 1) * (BN / 2) + wn * 32 + (lane & 31);
     }
 };

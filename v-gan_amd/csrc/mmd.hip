@@ -36,17 +36,17 @@ struct ColmaxJob {
     int lds, row_offset, n, d, from_softmax, nbx;  // nbx = ceil(d / 64); job is empty when S == nullptr
 };
 
-template <int VEC, bool CALIB>
-__global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ sq,
+template <int VEC, bool CALIB, int KW>
+__global__ __launch_bounds__(kBlock * KW, 2) void mmd_gram_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ sq,
                                                             int n, int p, const float* __restrict__ bw_ptr,
                                                             const TileDesc* __restrict__ tiles, int ntiles, float* __restrict__ Wg,
                                                             int ldw, int wrow0, float* __restrict__ partial, ColmaxJob cj) {
-    using G = GemmTile<GT, GT, GBK, KC, KC, VEC>;
+    using G = GemmTile<GT, GT, GBK * KW, KC, KC, VEC, 0, KW>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
-    __shared__ float red[8];
+    __shared__ float red[16];
     if ((int)blockIdx.x >= ntiles) {  // block-uniform
         const int cb = blockIdx.x - ntiles;
-        colmax_partial_body(cj.S, cj.lds, cj.row_offset, cj.part, cj.n, cj.d, cj.from_softmax, cb % cj.nbx, cb / cj.nbx);
+        colmax_partial_body<4 * KW>(cj.S, cj.lds, cj.row_offset, cj.part, cj.n, cj.d, cj.from_softmax, cb % cj.nbx, cb / cj.nbx);
         return;
     }
     const TileDesc td = tiles[blockIdx.x];
@@ -54,7 +54,8 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __rest
     zero_acc(acc);
     G::template run<false>(Z, ldz, Z, ldz, td.r0, td.c0, td.rlim, td.clim, p, lds, nullptr, acc);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, wid = threadIdx.x >> 6;
+    const int r_lo = G::first_reg();
     const int j = td.c0 + G::sub_col(0);
     const bool jok = j < td.clim;
     const float sj = jok ? sq[j] : 0.f;
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __rest
     const bool mirror = store && (td.flags & VGAN_TF_MIRROR);
     float wv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int rr = 0; rr < G::kNumRegs; ++rr) {
+        const int r = r_lo + rr;
         const int i = td.r0 + G::sub_row(0, r);
         const bool ok = jok && (i < td.rlim);
         const float si = (i < td.rlim) ? sq[i] : 0.f;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __rest
             const float K = ((t + t2) + (t4 + t8)) + t16;
             ksum += ok ? K : 0.f;
             const float w = wscale * (((0.25f * t + 0.5f * t2) + (t4 + 2.f * t8)) + 4.f * t16);
-            wv[r] = w;
+            wv[rr] = w;
             if (store && ok) Wg[(long)(i - wrow0) * ldw + j] = w;
         }
     }
@@ -94,14 +96,14 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __rest
             float* dst = Wg + (long)(j - wrow0) * ldw;
             const bool v4 = ((ldw & 3) == 0) && ((td.r0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i0 = ibase + 8 * q;
+            for (int qq = 0; qq < G::kNumRegs / 4; ++qq) {
+                const int i0 = ibase + 8 * (r_lo / 4 + qq);
                 if (v4 && i0 + 3 < td.rlim) {
-                    *reinterpret_cast<float4*>(dst + i0) = make_float4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+                    *reinterpret_cast<float4*>(dst + i0) = make_float4(wv[4 * qq], wv[4 * qq + 1], wv[4 * qq + 2], wv[4 * qq + 3]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (i0 + e < td.rlim) dst[i0 + e] = wv[4 * q + e];
+                        if (i0 + e < td.rlim) dst[i0 + e] = wv[4 * qq + e];
                 }
             }
         }
@@ -109,14 +111,18 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_kernel(const float* __rest
     ksum = wave_sum(ksum);
     lsum = wave_sum(lsum);
     if (lane == 0) {
-        red[wave] = ksum;
-        red[4 + wave] = lsum;
+        red[wid] = ksum;
+        red[8 + wid] = lsum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         float4 o;
         o.x = (red[0] + red[1]) + (red[2] + red[3]);
-        o.y = (red[4] + red[5]) + (red[6] + red[7]);
+        o.y = (red[8] + red[9]) + (red[10] + red[11]);
+        if (KW == 2) {
+            o.x += (red[4] + red[5]) + (red[6] + red[7]);
+            o.y += (red[12] + red[13]) + (red[14] + red[15]);
+        }
         // placement census (diagnostic only; never read by the product): HW_ID and XCC_ID of the wave that closed the tile
         o.z = __uint_as_float(__builtin_amdgcn_s_getreg((31 << 11) | 4));
         o.w = __uint_as_float(__builtin_amdgcn_s_getreg((31 << 11) | 20));
@@ -227,12 +233,12 @@ __global__ __launch_bounds__(1024) void mmd_finalize_kernel(const float* __restr
 
 // ---- backward: dZ_i = 2 (rowsum(Wg_i) z_i - (Wg . Z)_i), optionally times mul ---------------
 // A = Wg [nr, ncols] (KC), B(j = feature, k = Z row) = Z[k*ldz + j] (MC).
-template <int VEC>
-__global__ __launch_bounds__(kBlock, 2) void mmd_backward_kernel(const float* __restrict__ Wg, int ldw, const float* __restrict__ Z,
+template <int VEC, int KW>
+__global__ __launch_bounds__(kBlock * KW, 2) void mmd_backward_kernel(const float* __restrict__ Wg, int ldw, const float* __restrict__ Z,
                                                                 int ldz, int wrow0, int nr, int ncols, int p,
                                                                 const float* __restrict__ mul, int ldmul, float* __restrict__ out,
                                                                 int ldo, int kchunk, long slab_stride) {
-    using G = GemmTile<GT, GT, GBK, KC, MC, VEC>;
+    using G = GemmTile<GT, GT, GBK * KW, KC, MC, VEC, 0, KW>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float rs[GT];
     // XCD-aware tile order (speed only): block b runs on XCD b % 8; XCD x walks a contiguous chunk of a
@@ -262,8 +268,10 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_backward_kernel(const float* __
     }
     const int col = n0 + G::sub_col(0);
     if (col >= p) return;
+    const int r_lo = G::first_reg();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int rr = 0; rr < G::kNumRegs; ++rr) {
+        const int r = r_lo + rr;
         const int lrow = G::sub_row(0, r);
         const int row = m0 + lrow;
         if (row < nr) {
@@ -385,24 +393,46 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
     return count;
 }
 
+// Workgroup shape per kernel (A/B knobs).  Measured on MI355X at n = 1024, d = 784: the Gram (two tiles per CU) is faster
+// with 256-thread workgroups (48.7 vs 57.4 us), the backward GEMM (208 tiles for 256 CUs: one per CU) with 512-thread
+// K-split workgroups and no row slabs (48.9 vs 57.4 us; 50.4 with two slabs of 256-thread workgroups).
+static int env_kw(const char* name, int dflt) {
+    const char* v = getenv(name);
+    const int k = v ? atoi(v) : dflt;
+    return k == 1 || k == 2 ? k : dflt;
+}
+static int gram_kw() { static const int kw = env_kw("VGAN_GRAM_KW", 1); return kw; }
+static int bwd_kw() { static const int kw = env_kw("VGAN_BWD_KW", 2); return kw; }
+
+template <int KW>
+static void launch_gram_kw(dim3 grid, hipStream_t s, bool vec, int calibrate, const float* Z, int ldz, const float* sq, int n, int p,
+                           const float* bw, const TileDesc* td, int ntiles, float* Wg, int ldw, int wrow0, float* partial,
+                           const ColmaxJob& cj) {
+    dim3 block(kBlock * KW);
+    if (calibrate) {
+        if (vec)
+            hipLaunchKernelGGL((mmd_gram_kernel<4, true, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+        else
+            hipLaunchKernelGGL((mmd_gram_kernel<1, true, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((mmd_gram_kernel<4, false, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+        else
+            hipLaunchKernelGGL((mmd_gram_kernel<1, false, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+    }
+}
+
 static int launch_gram(const float* Z, int ldz, const float* sq, int n, int p, const float* bw, const int32_t* tiles, int ntiles,
                        int calibrate, float* Wg, int ldw, int wrow0, float* partial, const ColmaxJob& cj, int extra_blocks,
                        vgan_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const TileDesc* td = reinterpret_cast<const TileDesc*>(tiles);
     const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
-    dim3 grid(ntiles + extra_blocks), block(kBlock);
-    if (calibrate) {
-        if (vec)
-            hipLaunchKernelGGL((mmd_gram_kernel<4, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
-        else
-            hipLaunchKernelGGL((mmd_gram_kernel<1, true>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
-    } else {
-        if (vec)
-            hipLaunchKernelGGL((mmd_gram_kernel<4, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
-        else
-            hipLaunchKernelGGL((mmd_gram_kernel<1, false>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
-    }
+    dim3 grid(ntiles + extra_blocks);
+    if (gram_kw() == 2)
+        launch_gram_kw<2>(grid, s, vec, calibrate, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+    else
+        launch_gram_kw<1>(grid, s, vec, calibrate, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -474,14 +504,14 @@ extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int l
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (ncols % 4 == 0) && (ldw % 4 == 0) && (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Wg) && aligned16(Z);
-    const int kchunk = ((ncols + splits - 1) / splits + GBK - 1) / GBK * GBK;  // whole K tiles per slice (keeps 16-byte alignment)
-    dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT), splits), block(kBlock);
-    if (vec)
-        hipLaunchKernelGGL(mmd_backward_kernel<4>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo,
-                           kchunk, (long)slab_stride);
-    else
-        hipLaunchKernelGGL(mmd_backward_kernel<1>, grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo,
-                           kchunk, (long)slab_stride);
+    const int kw = bwd_kw();
+    const int kt = GBK * kw;
+    const int kchunk = ((ncols + splits - 1) / splits + kt - 1) / kt * kt;  // whole K tiles per slice (keeps 16-byte alignment)
+    dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT), splits), block(kBlock * kw);
+#define VGAN_BWD(V, W) hipLaunchKernelGGL((mmd_backward_kernel<V, W>), grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo, kchunk, (long)slab_stride)
+    if (kw == 2) { if (vec) VGAN_BWD(4, 2); else VGAN_BWD(1, 2); }
+    else { if (vec) VGAN_BWD(4, 1); else VGAN_BWD(1, 1); }
+#undef VGAN_BWD
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void mask_backward_kernel(const float* __re
 // column arg-max of U = (S < tau ? S : 1) over a chunk of rows: grid (ceil(d/64), chunks); body in vgan_common.hpp
 __global__ __launch_bounds__(kBlock) void colmax_partial_kernel(const float* __restrict__ S, int lds, int row_offset,
                                                                unsigned long long* __restrict__ part, int n, int d, int from_softmax) {
-    colmax_partial_body(S, lds, row_offset, part, n, d, from_softmax, blockIdx.x, blockIdx.y);
+    colmax_partial_body<4>(S, lds, row_offset, part, n, d, from_softmax, blockIdx.x, blockIdx.y);
 }
 __global__ void colmax_final_kernel(const unsigned long long* __restrict__ part, int chunks, unsigned long long* __restrict__ colkey,
                                     int d) {

@@ -66,17 +66,18 @@ __device__ __forceinline__ unsigned colkey_row(unsigned long long k) { return 0x
 // Column arg-max of U over one chunk of kColChunkRows rows for 64 columns (block bx covers columns 64*bx.., chunk by).
 // Shared by the stand-alone kernel (rows.hip) and by the Gram launch, which runs it in surplus workgroups.
 constexpr int kColChunkRows = 64;
+template <int NW>  // waves in the calling workgroup: ALL of them take part (rows are dealt round-robin over the waves)
 __device__ __forceinline__ void colmax_partial_body(const float* __restrict__ S, int lds, int row_offset,
                                                     unsigned long long* __restrict__ part, int n, int d, int from_softmax, int bx,
                                                     int by) {
-    __shared__ unsigned long long colmax_red[4][64];
+    __shared__ unsigned long long colmax_red[NW][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = bx * 64 + lane;
     const int r0 = by * kColChunkRows;
     const float tau = from_softmax ? 1.0f / (float)d : INFINITY;  // U given directly: no threshold
     unsigned long long best = 0ull;
     if (j < d) {
-        for (int r = r0 + wave; r < min(r0 + kColChunkRows, n); r += 4) {
+        for (int r = r0 + wave; r < min(r0 + kColChunkRows, n); r += NW) {
             const float sv = S[(long)r * lds + j];
             const unsigned long long k = colkey_pack(sv < tau ? sv : 1.0f, (unsigned)(row_offset + r));
             best = k > best ? k : best;
@@ -87,7 +88,7 @@ __device__ __forceinline__ void colmax_partial_body(const float* __restrict__ S,
     if (wave == 0 && j < d) {
         unsigned long long b = colmax_red[0][lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) b = colmax_red[w][lane] > b ? colmax_red[w][lane] : b;
+        for (int w = 1; w < NW; ++w) b = colmax_red[w][lane] > b ? colmax_red[w][lane] : b;
         part[(long)by * d + j] = b;
     }
 }

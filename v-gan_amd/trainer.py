@@ -161,9 +161,9 @@ class NoKLStepEngine:
         self.Z = torch.zeros(2 * n, dp, **f32)
         self.sqn = torch.zeros(2 * n, **f32)
         self.Wg = torch.zeros(nl, 2 * n, **f32)
-        # the backward GEMM contracts over the 2n rows of Z: sliced so that every SIMD holds several waves; the
-        # partial slabs are summed by the mask-backward kernel
-        self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", "2")))
+        # the backward GEMM contracts over the 2n rows of Z; it can be sliced into row slabs that the mask-backward kernel
+        # sums (VGAN_BWD_SPLITS), but its 512-thread K-split workgroups already hold four waves per SIMD: default 1
+        self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", "1")))
         self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
         self.gU = self.gU_slabs[0]
         self.dlogits = torch.zeros(nl, d, **f32)
