@@ -42,7 +42,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_engine(rank, world, use_graph):
+def build_engine(rank, world, use_graph, **engine_kw):
     import vgan_amd
     from vgan_amd import synth
     from vgan_amd.ops import HipOps
@@ -56,7 +56,7 @@ def build_engine(rank, world, use_graph):
     dev = torch.device("cuda", torch.cuda.current_device())
     eng = NoKLStepEngine(HipOps(), gen.to(dev), torch.as_tensor(data).to(dev), N_BATCH, EPOCH_BATCHES, lr=0.007,
                          weight_decay=0.04, penalty_weight=10.0, seed=777, noise="device", rank=rank, world=world,
-                         use_graph=use_graph)
+                         use_graph=use_graph, **engine_kw)
     return eng, data, params
 
 

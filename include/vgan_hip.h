@@ -162,6 +162,12 @@ int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int ntiles, co
                       int chunks, uint64_t* colkey, int n, int d, float weight, double* stats,
                       float* loss, float* loss_accum, float accum_scale, uint64_t* step_counter,
                       vgan_stream_t stream);
+/* Data-parallel step tail.  gathered: `world` records of 4 + d 64-bit words, record r = rank r's
+ * {stats[4] as f64 bits, colkey[d]} (what one all-gather delivers).  Sums the statistics in rank order,
+ * takes the per-column maximum of the keys, writes stats / colkey and finishes the loss as vgan_mmd_loss does. */
+int vgan_mmd_finalize_ranks(const uint64_t* gathered, int world, int d, int n, float weight, double* stats,
+                            uint64_t* colkey, float* loss, float* loss_accum, float accum_scale,
+                            uint64_t* step_counter, vgan_stream_t stream);
 /* dZ[i - wrow0, :] = 2 (rowsum(Wg_i) z_i - Wg_i . Z) for the nr rows starting at wrow0;
  * if mul != NULL the result is multiplied elementwise by mul[i - wrow0, :] (the `U * batch`
  * product rule: gU = dY * X).  Z is [ncols, p], Wg is [nr, ncols].

@@ -134,6 +134,13 @@ class CpuOps:
             colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
         self.mmd_loss(stats, colkey if colpart is not None else None, n, d, weight, loss, loss_accum, accum_scale, step_counter)
 
+    def mmd_finalize_ranks(self, gathered, world, d, n, weight, stats, colkey, loss, loss_accum=None, accum_scale=1.0,
+                           step_counter=None):
+        g = gathered.reshape(world, 4 + d)
+        stats.copy_(g[:, :4].contiguous().view(torch.float64).sum(0))
+        colkey.copy_(torch.as_tensor(g[:, 4:].numpy().view(np.uint64).max(axis=0).view(np.int64)))
+        self.mmd_loss(stats, colkey, n, d, weight, loss, loss_accum, accum_scale, step_counter)
+
     def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits, nslabs=1, slab_stride=0):
         s = _np(S).astype(np.float32)
         n, d = s.shape

@@ -11,23 +11,14 @@ import torch
 import torch.distributed as dist
 
 import bench
-from vgan_amd.trainer import NoKLStepEngine
 
 rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
 
-class ForcedDP(NoKLStepEngine):
-    """world_size 1 normally takes the single-rank shortcuts; this forces the exchange code path."""
-
-
 for graph in (False, True):
-    eng, data, params = bench.build_engine(rank, world, graph)
-    if world == 1:
-        eng.world = 2          # take the DP branches ...
-        eng._real_world = 1    # ... while the process group has one member (all-gather/all-reduce of one)
-        eng.nl, eng.lo = eng.n, 0
+    eng, data, params = bench.build_engine(rank, world, graph, force_exchange=True)
     losses = []
     for t in range(6):
         if t % bench.EPOCH_BATCHES == 0:

@@ -143,6 +143,13 @@ class HipOps:
                                               int(n), int(d), float(weight), _ptr(stats), _ptr(loss), _ptr(loss_accum),
                                               float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_finalize")
 
+    def mmd_finalize_ranks(self, gathered, world, d, n, weight, stats, colkey, loss, loss_accum=None, accum_scale=1.0,
+                           step_counter=None):
+        assert gathered.dtype == torch.int64 and gathered.numel() >= world * (4 + d)
+        _lib.check(self.lib.vgan_mmd_finalize_ranks(_ptr(gathered), int(world), int(d), int(n), float(weight), _ptr(stats),
+                                                    _ptr(colkey), _ptr(loss), _ptr(loss_accum), float(accum_scale),
+                                                    _ptr(step_counter), self._stream()), "vgan_mmd_finalize_ranks")
+
     def mask_from_softmax(self, S, U):
         _mat(S, "S"), _mat(U, "U")
         n, d = S.shape

@@ -25,9 +25,9 @@ Generator (src/models/Generator.py:58-70 has NO activation between its Linear la
                (different fp32 association; parity-tested like the layered path).
 
 Data parallel (exact): rank r owns rows [r*n/G, (r+1)*n/G) of the batch.  Exchange per
-step: all-gather of the Y rows (+ their norms), all-reduce(MAX) of the packed column arg-max keys,
-all-reduce(SUM) of the four block statistics, all-reduce(SUM) of the generator gradient (the flat
-gradient when layered; only M4, 10x smaller, when collapsed).  Every rank applies the identical
+step -- three small collectives: all-gather of the Y rows, all-gather of one {4 block statistics | d packed
+column arg-max keys} record per rank (folded in rank order by vgan_mmd_finalize_ranks), all-reduce(SUM)
+of the generator gradient (the flat gradient when layered; only M4, 10x smaller, when collapsed).  Every rank applies the identical
 Adadelta update.  The data set and the noise stream are replicated, so results do not depend on G.
 
 Measured and rejected (MI355X, ROCm 7.2, c3): a fork/join HIP graph (XX tiles and weight-gradient GEMMs
@@ -78,10 +78,12 @@ class FlatParams:
 class NoKLStepEngine:
     def __init__(self, ops, generator, data, batch_size, batches_per_epoch, lr=0.007, weight_decay=0.04, penalty_weight=10.0,
                  seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None,
-                 generator_mode=None):
+                 generator_mode=None, force_exchange=False):
         self.ops = ops
         self.dev = data.device
         self.rank, self.world, self.group = rank, world, group
+        # take the data-parallel exchange path (collectives included) even with one rank: lets a single GPU exercise it
+        self.exchange = world > 1 or bool(force_exchange)
         n = self.n = int(batch_size)
         if n % world != 0:
             raise ValueError(f"global batch {n} must be divisible by the number of ranks {world}")
@@ -179,6 +181,12 @@ class NoKLStepEngine:
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.colpart = torch.zeros(ops.colmax_chunks(nl) * d, dtype=torch.int64, device=self.dev)
         self.colkey = torch.zeros(d, dtype=torch.int64, device=self.dev)
+        if self.exchange:
+            # one exchange record per rank: {block statistics (4 f64) | column arg-max keys (d u64)} -> ONE all-gather
+            self.xrec = torch.zeros(4 + d, dtype=torch.int64, device=self.dev)
+            self.xstats = self.xrec[:4].view(torch.float64)
+            self.xkeys = self.xrec[4:]
+            self.xall = torch.zeros(world, 4 + d, dtype=torch.int64, device=self.dev)
 
     # ---- host-side controls ---------------------------------------------------------------------
     def set_epoch_batches(self, idx):
@@ -204,7 +212,7 @@ class NoKLStepEngine:
         """Gradient of parameter tensor k as of the last step (sums split-K slabs that Adadelta consumed directly)."""
         if self.mode == "collapsed":
             self.ops.homogeneous_pack(self.unpack_layers, unpack=True)  # packed gradients -> flat layout (inspection only)
-        elif self.world == 1 and self.splits > 1:
+        elif not self.exchange and self.splits > 1:
             return sum(self.fp.view(self.gslab[sl], k) for sl in range(self.splits))
         return self.fp.view(self.fp.grad, k)
 
@@ -246,7 +254,7 @@ class NoKLStepEngine:
                     ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
                 dist.all_reduce(self.fp.grad, group=self.group)
                 ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, **adadelta)
-            elif self.splits > 1:  # single rank: Adadelta sums the slabs itself
+            elif self.splits > 1:  # no exchange: Adadelta sums the slabs itself
                 ops.adadelta_step(self.fp.flat, self.gslab[0], self.fp.sq, self.fp.acc, nslabs=self.splits, slab_stride=self.fp.total,
                                   **adadelta)
             else:
@@ -279,7 +287,7 @@ class NoKLStepEngine:
             ops.noise_normal(self.za, self.seed, self.step_counter, 0, cols=self.L, ones_col=self.L)
         self._generator_forward()
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
-        if self.world == 1:
+        if not self.exchange:
             ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n],
                                      self.sqn[n:], row_offset=0, **rowsel)
         else:
@@ -288,14 +296,14 @@ class NoKLStepEngine:
             ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, None, self.Z[n + lo:n + lo + nl], None,
                                      self.sqn[n + lo:n + lo + nl], row_offset=lo, **rowsel)
             dist.all_gather_into_tensor(self.Z[n:], self.Z[n + lo:n + lo + nl], group=self.group)
-            dist.all_gather_into_tensor(self.sqn[n:], self.sqn[n + lo:n + lo + nl], group=self.group)
+            ops.row_sqnorm(self.Z[n:], self.sqn[n:], self.dp)  # norms of all Y rows: a 5 us kernel instead of a second collective
 
     def _calibrate(self):
         """First-call bandwidth (src/models/Mmd_loss_constrained.py:16-20): sum(L) / (N^2 - N)."""
         ops = self.ops
         ops.mmd_gram(self.Z, self.sqn, self.n, self.dp, None, self.tiles, True, None, 0, self.partial)
         ops.mmd_reduce(self.partial, self.tiles, self.stats, True)
-        if self.world > 1:
+        if self.exchange:
             dist = self._collect()
             dist.all_reduce(self.stats, group=self.group)
         ops.mmd_set_bandwidth(self.stats, self.n, self.bw)
@@ -303,7 +311,7 @@ class NoKLStepEngine:
 
     def _loss_backward_update(self):
         ops, n, nl, lo, d = self.ops, self.n, self.nl, self.lo, self.d
-        dist = self._collect() if self.world > 1 else None
+        dist = self._collect() if self.exchange else None
         gstride = nl * self.dp
         if dist is None:
             ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, lo,
@@ -311,12 +319,12 @@ class NoKLStepEngine:
             ops.mmd_finalize(self.partial, self.tiles, self.colpart, ops.colmax_chunks(nl), self.colkey, n, d, self.pen, self.stats,
                              self.loss, self.loss_accum, self.accum_scale, self.step_counter)
         else:
-            ops.colmax(self.S, lo, self.colpart, self.colkey, True)
-            dist.all_reduce(self.colkey, op=dist.ReduceOp.MAX, group=self.group)
+            ops.colmax(self.S, lo, self.colpart, self.xkeys, True)
             ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
-            ops.mmd_reduce(self.partial, self.tiles, self.stats, True)
-            dist.all_reduce(self.stats, group=self.group)
-            ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+            ops.mmd_reduce(self.partial, self.tiles, self.xstats, True)
+            dist.all_gather_into_tensor(self.xall.view(-1), self.xrec, group=self.group)
+            ops.mmd_finalize_ranks(self.xall, self.world, d, n, self.pen, self.stats, self.colkey, self.loss, self.loss_accum,
+                                   self.accum_scale, self.step_counter)
         ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride)
         ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         self._generator_backward_update(dist)
