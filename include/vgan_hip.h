@@ -177,6 +177,27 @@ int vgan_mmd_finalize_ranks(const uint64_t* gathered, int world, int d, int n, f
 int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr,
                       int ncols, int p, const float* mul, int ldmul, float* out, int ldo,
                       int splits, int64_t slab_stride, vgan_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * Split-bf16 ("bf16x3") variants of the two dense contractions, for large problems (opt-in precision
+ * mode): every operand z = hi + lo with hi = bf16(z), lo = bf16(z - hi), products hi.hi' + hi.lo' + lo.hi'
+ * on the bf16 MFMA (16x the fp32 MFMA rate) with fp32 accumulation: ~3e-7 relative on a Gram entry at
+ * K = 784.  The fused epilogues are those of the fp32 kernels.
+ * ------------------------------------------------------------------------------------------- */
+/* Z [rows, ldz] (first p columns) -> Zh, Zl [rows, kp] bf16 bit patterns (kp = p rounded up to 64, pad = 0)
+ * and, unless NULL, the transposed images ZTh, ZTl [kp, kn] (kn = rows rounded up to 64, pad = 0). */
+int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, uint16_t* Zh, uint16_t* Zl, int kp,
+                         uint16_t* ZTh, uint16_t* ZTl, int kn, vgan_stream_t stream);
+/* vgan_mmd_gram_colmax on the split operands; the gradient weights leave as a bf16 hi/lo pair Wh, Wl
+ * [nr, ldw] (ldw >= 2n rounded up to 64; columns >= 2n must be pre-zeroed).  S may be NULL (no column job). */
+int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
+                      const int32_t* tiles, int ntiles, uint16_t* Wh, uint16_t* Wl, int ldw, int wrow0,
+                      float* partial, const float* S, int lds, int from_softmax, int row_offset,
+                      uint64_t* colpart, int nrows, int d, vgan_stream_t stream);
+/* vgan_mmd_backward on the split operands: out = 2 (rowsum(W) z - W . Z) * mul with W = Wh + Wl [nr, kn]
+ * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue. */
+int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh,
+                          const uint16_t* ZTl, int kn, int kp, const float* Z, int ldz, int wrow0, int nr,
+                          int p, const float* mul, int ldmul, float* out, int ldo, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

@@ -231,6 +231,64 @@ class CpuOps:
             o = torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + sl * slab_stride)
             o[:nr, :p].copy_(torch.as_tensor(r))
 
+    # ---- split-bf16 MMD: emulated with torch.bfloat16 roundings; products hi.hi + hi.lo + lo.hi in float64
+    @staticmethod
+    def _split(x):
+        hi = torch.as_tensor(x, dtype=torch.float32).to(torch.bfloat16)
+        lo = (torch.as_tensor(x, dtype=torch.float32) - hi.float()).to(torch.bfloat16)
+        return hi, lo
+
+    def mmd_bf3_prepare(self, Z, rows, p, Zh, Zl, ZTh=None, ZTl=None):
+        hi, lo = self._split(Z[:rows, :p])
+        Zh.zero_(), Zl.zero_()
+        Zh[:rows, :p] = hi.view(torch.int16)
+        Zl[:rows, :p] = lo.view(torch.int16)
+        if ZTh is not None:
+            ZTh.zero_(), ZTl.zero_()
+            ZTh[:p, :rows] = hi.t().contiguous().view(torch.int16)
+            ZTl[:p, :rows] = lo.t().contiguous().view(torch.int16)
+
+    @staticmethod
+    def _bf(t):
+        return t.view(torch.bfloat16).double().numpy()
+
+    def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True):
+        zh, zl = self._bf(Zh), self._bf(Zl)
+        s = _np(sq).astype(np.float64)
+        bwv = float(bw.reshape(-1)[0])
+        part = np.zeros((tiles.shape[0], 4), dtype=np.float32)
+        for t, (r0, c0, rlim, clim, fl, *_rest) in enumerate(tiles.tolist()):
+            ri, cj = np.arange(r0, min(r0 + 64, rlim)), np.arange(c0, min(c0 + 64, clim))
+            g = zh[ri] @ zh[cj].T + zh[ri] @ zl[cj].T + zl[ri] @ zh[cj].T
+            L = np.maximum(s[ri][:, None] + s[cj][None, :] - 2 * g, 0.0)
+            K = np.zeros_like(L)
+            dK = np.zeros_like(L)
+            for sc in orc.rbf_scales(bwv, np.float64):
+                e = np.exp(-L / sc)
+                K += e
+                dK -= e / sc
+            part[t, 0] = K.sum()
+            if (fl & TF_STORE) and Wh is not None:
+                w = (-1.0 if fl & TF_NEG else 1.0) * 2.0 / (n * n) * dK
+                hi, lo = self._split(w)
+                Wh[np.ix_(ri - wrow0, cj)] = hi.view(torch.int16)
+                Wl[np.ix_(ri - wrow0, cj)] = lo.view(torch.int16)
+                if fl & TF_MIRROR:
+                    Wh[np.ix_(cj - wrow0, ri)] = hi.t().contiguous().view(torch.int16)
+                    Wl[np.ix_(cj - wrow0, ri)] = lo.t().contiguous().view(torch.int16)
+        partial.reshape(-1, 4)[:tiles.shape[0]].copy_(torch.as_tensor(part))
+        if S is not None:
+            self.colmax_partial(S, row_offset, colpart, from_softmax)
+
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out):
+        wh, wl, th, tl = self._bf(Wh)[:nr], self._bf(Wl)[:nr], self._bf(ZTh)[:p], self._bf(ZTl)[:p]
+        prod = wh @ th.T + wh @ tl.T + wl @ th.T
+        z = _np(Z)[wrow0:wrow0 + nr, :p].astype(np.float64)
+        r = 2.0 * ((wh + wl).sum(1, keepdims=True) * z - prod)
+        if mul is not None:
+            r = r * _np(mul)[:nr, :p]
+        out[:nr, :p].copy_(torch.as_tensor(r))
+
     # ---- optimiser / noise
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         if nslabs > 1:

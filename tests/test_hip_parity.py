@@ -462,3 +462,81 @@ def test_c2_fit_end_to_end_device_noise():
     u = model.generate_subspaces(100)
     assert u.shape == (100, 166) and u.dtype == torch.bool and u.any(dim=1).all()
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
+# ------------------------------------------------------------------------------ split-bf16 ("bf16x3") MMD mode
+def test_bf3_prepare_and_kernels_vs_fp64(ops):
+    n, d = 1024, 784
+    rng = np.random.default_rng(21)
+    X = orc.synthetic_dataset("c3", rows=n, seed=5)
+    U = np.where(rng.random((n, d)) < 0.5, 1.0, rng.random((n, d)) * 1e-3).astype(np.float32)
+    Y = U * X
+    kp, kn = 832, 2048
+    Z = torch.zeros(2 * n, d, device="cuda")
+    Z[:n], Z[n:] = dev(X), dev(Y)
+    i16 = dict(dtype=torch.int16, device="cuda")
+    Zh, Zl, ZTh, ZTl = (torch.full((2 * n, kp), 7, **i16), torch.full((2 * n, kp), 7, **i16), torch.full((kp, kn), 7, **i16),
+                        torch.full((kp, kn), 7, **i16))
+    ops.mmd_bf3_prepare(Z, 2 * n, d, Zh, Zl, ZTh, ZTl)
+    zh, zl = Zh.view(torch.bfloat16).float(), Zl.view(torch.bfloat16).float()
+    assert torch.equal(zh[:, :d], Z.to(torch.bfloat16).float())                       # hi = RNE bf16 of z
+    assert float((zh[:, :d] + zl[:, :d] - Z).abs().max()) <= 2.0 ** -16 * float(Z.abs().max())
+    assert float(zh[:, d:].abs().max()) == 0 and float(zl[:, d:].abs().max()) == 0
+    assert torch.equal(ZTh[:, :2 * n], Zh.t()) and torch.equal(ZTl[:, :2 * n], Zl.t())
+    # Gram + backward on the split operands against the fp64 oracle
+    sq = torch.empty(2 * n, device="cuda")
+    ops.row_sqnorm(Z, sq, d)
+    f = orc.mmd_forward(X.astype(np.float64), Y.astype(np.float64), U.astype(np.float64), 0.0)
+    bw = torch.full((1,), float(f["bw"]), device="cuda")
+    tiles = ops.build_tiles(n, 1)
+    partial = torch.empty(tiles.shape[0], 4, device="cuda")
+    Wh, Wl = torch.zeros(n, kn, **i16), torch.zeros(n, kn, **i16)
+    ops.mmd_gram_bf3(Zh, Zl, sq, n, bw, tiles, Wh, Wl, n, partial)
+    stats = torch.empty(4, dtype=torch.float64, device="cuda")
+    ops.mmd_reduce(partial, tiles, stats)
+    st = host(stats) / (float(n) * n)
+    assert abs((st[0] - 2 * st[1] + st[2]) - f["mmd2"]) < 2e-5
+    np.testing.assert_allclose(st[:3], [f["xx"], f["xy"], f["yy"]], rtol=2e-5)
+    out = torch.empty(n, d, device="cuda")
+    ops.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, n, n, d, None, out)
+    dY, _ = orc.mmd_backward(X.astype(np.float64), Y.astype(np.float64), U.astype(np.float64), 0.0, f["bw"])
+    np.testing.assert_allclose(host(out), dY, rtol=0, atol=1e-3 * np.abs(dY).max())
+
+
+@pytest.mark.parametrize("mode", ["collapsed"])
+def test_c3_step_bf16x3_vs_fp64_reference(ops, mode):
+    """The metric configuration in split-bf16 mode: loss within the 1e-4 bar of the reference's fp64 value."""
+    g = load_golden("f5_c3_scalars.npz")
+    n, d = 1024, 784
+    data = orc.synthetic_dataset("c3", rows=2048)[:n]
+    z = np.random.default_rng(5).normal(size=(n, orc.latent_size(d))).astype(np.float32)
+    eng, _ = make_engine(ops, orc.synthetic_generator_params(d), data, n, generator_mode=mode, mmd_precision="bf16x3")
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    eng.set_noise(torch.as_tensor(z))
+    eng.step()
+    assert abs(float(eng.loss) - float(g["loss_f64"])) < 1e-4, float(eng.loss) - float(g["loss_f64"])
+    for i in range(8):
+        gn = np.sqrt((host(eng.grad_view(i)).astype(np.float64) ** 2).sum())
+        np.testing.assert_allclose(gn, float(g[f"gnorm_f64_{i}"]), rtol=5e-3)
+    np.testing.assert_allclose(host(eng.grad_view(6))[:8, :16], g["g6slice_f64"], rtol=0, atol=5e-3 * np.abs(g["g6slice_f64"]).max())
+
+
+def test_trajectory_c2_like_bf16x3_vs_oracle(ops):
+    """Six steps at d=166, batch=500 (ragged tiles) in split-bf16 mode against the fp64 oracle."""
+    n, d, rows = 500, 166, 1500
+    rng = np.random.default_rng(99)
+    data = (rng.normal(size=(rows, d)) * rng.uniform(0.5, 2.0, size=(1, d))).astype(np.float32)
+    params = orc.synthetic_generator_params(d, seed=3)
+    L = orc.latent_size(d)
+    eng, _ = make_engine(ops, params, data, n, nb=3, graph=True, mmd_precision="bf16x3")
+    ref = orc.NoKLTrainer([p.astype(np.float64) for p in params])
+    perm = np.stack([rng.permutation(rows)[:n] for _ in range(3)])
+    eng.set_epoch_batches(torch.as_tensor(perm))
+    for t in range(6):
+        z = rng.normal(size=(n, L)).astype(np.float32)
+        eng.set_noise(torch.as_tensor(z))
+        eng.step()
+        want = ref.step(data[perm[t % 3]].astype(np.float64), z.astype(np.float64))
+        assert abs(float(eng.loss) - want["loss"]) < 1e-4, (t, float(eng.loss), want["loss"])
+    for i in range(8):
+        np.testing.assert_allclose(host(eng.fp.view(eng.fp.flat, i)), ref.params[i], rtol=0, atol=1e-4)

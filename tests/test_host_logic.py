@@ -71,6 +71,21 @@ def test_engine_two_steps_vs_reference_fixture(cfg, mode):
     np.testing.assert_allclose(float(eng.bw), float(g["bw"]), rtol=1e-5)
 
 
+def test_engine_bf16x3_precision_mode_vs_reference_fixture():
+    """Split-bf16 MMD mode (emulated on the CPU stand-in with torch.bfloat16 roundings): the step still meets the loss bar."""
+    g = load_golden("f2_step_c2.npz")
+    n = g["batch"].shape[0]
+    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], n, 1, mmd_precision="bf16x3")
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    for step in range(2):
+        eng.set_noise(torch.as_tensor(g["noise"]))
+        eng.step()
+        assert abs(float(eng.loss) - float(g[f"loss{step}"])) < 1e-4
+        for i in range(8):
+            ref = g[f"grad{step}_{i}"]
+            np.testing.assert_allclose(eng.grad_view(i).numpy(), ref, rtol=0, atol=2e-3 * max(np.abs(ref).max(), 1e-8))
+
+
 def test_fit_loop_reproduces_reference_run_on_cpu_provider():
     """The whole VGAN_no_kl.fit host loop (seeding, init order, shuffles, noise draws, epoch means, shared-RBF
     bandwidth hand-over, sampling) against the reference's own run (fixture f3), kernels emulated by CpuOps."""

@@ -12,13 +12,9 @@
 #include <vector>
 
 #include "gemm_core.hpp"
+#include "mmd_common.hpp"
 
 namespace vgan {
-
-struct TileDesc {
-    int r0, c0, rlim, clim, flags, pad0, pad1, pad2;
-};
-static_assert(sizeof(TileDesc) == VGAN_TILE_INTS * 4, "tile descriptor layout");
 
 constexpr int GT = VGAN_TILE;  // 64 x 64 Gram tile: one 32x32 MFMA sub-tile per wave
 constexpr int GBK = 32;  // 128-byte row segments per staging load (one full L2 line)
@@ -27,15 +23,6 @@ constexpr int GBK = 32;  // 128-byte row segments per staging load (one full L2 
 // CALIB: only sum of L (first-call bandwidth).  Otherwise: sum of K = t + t^2 + t^4 + t^8 + t^16 with
 // t = exp(-L / (4 bw)), i.e. sum_k exp(-L / (bw m_k)), m = {4, 2, 1, .5, .25}, and (optionally) the
 // gradient weights Wg = sgn * (2/n^2) * dK/dL with dK/dL = -(1/bw) (t/4 + t^2/2 + t^4 + 2 t^8 + 4 t^16).
-// Column arg-max job that may ride in the Gram launch: workgroups with blockIdx.x >= ntiles each do one (64-column,
-// 64-row-chunk) cell of it.  It is independent of the Gram, tiny, and the Gram grid (528 tiles at n = 1024) leaves most
-// CUs idle during its last third, so this removes a launch from the step's critical path for free.
-struct ColmaxJob {
-    const float* S;
-    unsigned long long* part;
-    int lds, row_offset, n, d, from_softmax, nbx;  // nbx = ceil(d / 64); job is empty when S == nullptr
-};
-
 template <int VEC, bool CALIB, int KW>
 __global__ __launch_bounds__(kBlock * KW, 2) void mmd_gram_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ sq,
                                                             int n, int p, const float* __restrict__ bw_ptr,

@@ -203,6 +203,31 @@ class HipOps:
                                               _ptr(mul), ldmul, _ptr(out), out.stride(0), int(splits), int(slab_stride),
                                               self._stream()), "vgan_mmd_backward")
 
+    # ---- split-bf16 MMD (opt-in precision mode) ------------------------------------------------------
+    def mmd_bf3_prepare(self, Z, rows, p, Zh, Zl, ZTh=None, ZTl=None):
+        _mat(Z, "Z")
+        for t in (Zh, Zl, ZTh, ZTl):
+            assert t is None or (t.dtype == torch.int16 and t.is_cuda and t.stride(1) == 1)
+        kn = ZTh.stride(0) if ZTh is not None else 0
+        _lib.check(self.lib.vgan_mmd_bf3_prepare(_ptr(Z), Z.stride(0), int(rows), int(p), _ptr(Zh), _ptr(Zl), Zh.stride(0),
+                                                 _ptr(ZTh), _ptr(ZTl), kn, self._stream()), "vgan_mmd_bf3_prepare")
+
+    def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True):
+        ntiles = tiles.shape[0]
+        nrows, d = (S.shape if S is not None else (0, 0))
+        ldw = Wh.stride(0) if Wh is not None else 0
+        _lib.check(self.lib.vgan_mmd_gram_bf3(_ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(sq), int(n), _ptr(bw), _ptr(tiles), ntiles,
+                                              _ptr(Wh), _ptr(Wl), ldw, int(wrow0), _ptr(partial), _ptr(S),
+                                              S.stride(0) if S is not None else 0, int(bool(from_softmax)), int(row_offset),
+                                              _ptr(colpart), nrows, d, self._stream()), "vgan_mmd_gram_bf3")
+
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out):
+        _mat(Z, "Z"), _mat(out, "out")
+        ldmul = mul.stride(0) if mul is not None else 0
+        _lib.check(self.lib.vgan_mmd_backward_bf3(_ptr(Wh), _ptr(Wl), Wh.stride(0), _ptr(ZTh), _ptr(ZTl), ZTh.stride(0),
+                                                  ZTh.shape[0], _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul,
+                                                  _ptr(out), out.stride(0), self._stream()), "vgan_mmd_backward_bf3")
+
     # ---- optimiser / noise / misc ----------------------------------------------------------------
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         """nslabs > 1: `g` is slab 0 of split-K gradient slabs `slab_stride` apart, summed inside the kernel."""

@@ -78,7 +78,7 @@ class FlatParams:
 class NoKLStepEngine:
     def __init__(self, ops, generator, data, batch_size, batches_per_epoch, lr=0.007, weight_decay=0.04, penalty_weight=10.0,
                  seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None,
-                 generator_mode=None, force_exchange=False):
+                 generator_mode=None, force_exchange=False, mmd_precision=None):
         self.ops = ops
         self.dev = data.device
         self.rank, self.world, self.group = rank, world, group
@@ -169,6 +169,17 @@ class NoKLStepEngine:
         self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
         self.gU = self.gU_slabs[0]
         self.dlogits = torch.zeros(nl, d, **f32)
+        # MMD arithmetic: "fp32" (fp32 MFMA, default) or "bf16x3" (split-bf16 operands on the bf16 MFMA, see
+        # csrc/mmd_bf16.hip: ~3e-7 relative on a Gram entry at K = 784, a third of the time)
+        self.precision = mmd_precision or os.environ.get("VGAN_MMD_PRECISION", "fp32")
+        if self.precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"mmd_precision must be 'fp32' or 'bf16x3', got {self.precision!r}")
+        if self.precision == "bf16x3":
+            i16 = dict(dtype=torch.int16, device=self.dev)
+            self.kp, self.kn = (d + 63) // 64 * 64, (2 * n + 63) // 64 * 64
+            self.Zh, self.Zl = torch.zeros(2 * n, self.kp, **i16), torch.zeros(2 * n, self.kp, **i16)
+            self.ZTh, self.ZTl = torch.zeros(self.kp, self.kn, **i16), torch.zeros(self.kp, self.kn, **i16)
+            self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev)
         self.partial = torch.zeros(self.tiles.shape[0], 4, **f32)
@@ -313,20 +324,34 @@ class NoKLStepEngine:
         ops, n, nl, lo, d = self.ops, self.n, self.nl, self.lo, self.d
         dist = self._collect() if self.exchange else None
         gstride = nl * self.dp
+        bf3 = self.precision == "bf16x3"
+        if bf3:
+            ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
         if dist is None:
-            ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, lo,
-                                self.colpart, True)
+            if bf3:
+                ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial, self.S, lo,
+                                 self.colpart, True)
+            else:
+                ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, lo,
+                                    self.colpart, True)
             ops.mmd_finalize(self.partial, self.tiles, self.colpart, ops.colmax_chunks(nl), self.colkey, n, d, self.pen, self.stats,
                              self.loss, self.loss_accum, self.accum_scale, self.step_counter)
         else:
             ops.colmax(self.S, lo, self.colpart, self.xkeys, True)
-            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
+            if bf3:
+                ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial)
+            else:
+                ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
             ops.mmd_reduce(self.partial, self.tiles, self.xstats, True)
             dist.all_gather_into_tensor(self.xall.view(-1), self.xrec, group=self.group)
             ops.mmd_finalize_ranks(self.xall, self.world, d, n, self.pen, self.stats, self.colkey, self.loss, self.loss_accum,
                                    self.accum_scale, self.step_counter)
-        ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride)
-        ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
+        if bf3:
+            ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU)
+            ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits)
+        else:
+            ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride)
+            ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         self._generator_backward_update(dist)
 
     def _step_body(self):
