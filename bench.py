@@ -10,7 +10,8 @@ One step = one VGAN_no_kl.fit step body (reference src/vgan.py:597-621) at the G
 the batch rows across ranks (exact data parallel; strong scaling: total work fixed).
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
-  roofline      the Gram/MMD kernel against the fp32-MFMA peak (durations measured here with HIP events)
+  roofline      the Gram/MMD kernel of the active precision mode against the MFMA peak of the instruction it issues
+                (durations measured here with HIP events); the other mode's kernels are timed beside it
   cpu_baseline  the op-for-op PyTorch-CPU port of the reference step timed on this host's cores
   parity        |loss_gpu - loss_cpu| on identical inputs (bar 1e-4)
 """
@@ -28,7 +29,8 @@ import torch  # noqa: E402
 
 N_BATCH, D_FEAT, EPOCH_BATCHES = 1024, 784, 16
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
-WORKLOAD = "configs[2]: MNIST-pixels-as-features stand-in, d=784, batch=1024 (VGAN_no_kl step, fp32)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+WORKLOAD = "configs[2]: MNIST-pixels-as-features stand-in, d=784, batch=1024 (VGAN_no_kl step)"
 
 
 def parse():
@@ -41,6 +43,8 @@ def parse():
                          "W warm-up steps; a fit runs for minutes, so the ramped state is the representative one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3"], default=None,
+                    help="MMD contraction mode (default: VGAN_MMD_PRECISION or the engine's 'auto' rule, bf16x3 at this size)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -85,18 +89,27 @@ def time_kernel(fn, iters=30):
 
 
 def kernel_rooflines(eng):
-    """Per-launch durations of the two MFMA kernels of the MMD, as launched inside the step."""
-    ops, n, p = eng.ops, eng.n, eng.dp
-    nl = eng.nl
-    t_gram = time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, eng.tiles, False, eng.Wg, n + eng.lo, eng.partial))
-    t_bwd = time_kernel(lambda: ops.mmd_backward(eng.Wg, eng.Z, n + eng.lo, nl, 2 * n, p, eng.Z[eng.lo:eng.lo + nl], eng.gU))
+    """Per-launch durations of the MFMA kernels of the MMD, as launched inside the step (both precision modes)."""
+    ops, n, p, d = eng.ops, eng.n, eng.dp, eng.d
+    nl, lo = eng.nl, eng.lo
     # algorithmic FLOPs (SURVEY 8d): forward 2n^2 unique pairs x 2p = 4 n^2 p ; backward Gs[n x 2n] . Z[2n x p] = 4 n^2 p
-    f_gram = 4.0 * n * n * D_FEAT / eng.world
-    f_bwd = 4.0 * n * n * D_FEAT / eng.world
-    return {
-        "mmd_gram": {"ms": t_gram, "tflops": f_gram / (t_gram * 1e-3) / 1e12, "flop": f_gram},
-        "mmd_backward": {"ms": t_bwd, "tflops": f_bwd / (t_bwd * 1e-3) / 1e12, "flop": f_bwd},
-    }
+    flop = 4.0 * n * n * D_FEAT / eng.world
+    out = {}
+
+    def add(name, ms):
+        out[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "flop": flop}
+
+    Wg = eng.Wg if not eng.bf3 else torch.zeros(nl, 2 * n, device=eng.Z.device)
+    add("mmd_gram_kernel<4,false,1>", time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, eng.tiles, False, Wg, n + lo, eng.partial)))
+    add("mmd_backward_kernel<4,2>", time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU)))
+    if eng.bf3:
+        gs = nl * eng.dp
+        add("mmd_gram_bf3_kernel<64>", time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles, eng.Wh, eng.Wl,
+                                                                         n + lo, eng.partial)))
+        add("mmd_backward_bf3_kernel<64>", time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d,
+                                                                                 eng.Z[lo:lo + nl], eng.gU, eng.bsplits, gs)))
+        out["bf3_prepare_kernel"] = {"ms": time_kernel(lambda: ops.mmd_bf3_prepare(eng.Z, 2 * n, d, eng.Zh, eng.Zl, eng.ZTh, eng.ZTl))}
+    return out
 
 
 def usable_cores():
@@ -136,7 +149,7 @@ def cpu_baseline(data, params, seconds):
             "sample": f"{k} VGAN_no_kl steps (batch=1024, d=784, fp32) of the PyTorch-CPU port in {dt:.1f} s"}, first_loss, (X, z)
 
 
-def gpu_first_loss(params, X, z):
+def gpu_first_loss(params, X, z, **engine_kw):
     """Loss of the first step on the same params / batch / noise as the CPU probe."""
     import vgan_amd
     from vgan_amd.ops import HipOps
@@ -145,7 +158,8 @@ def gpu_first_loss(params, X, z):
     with torch.no_grad():
         for q, v in zip(gen.parameters(), params):
             q.copy_(torch.as_tensor(v))
-    eng = NoKLStepEngine(HipOps(), gen.cuda(), X.cuda(), N_BATCH, 1, noise="host", use_graph=False, loss_accum_scale=1.0)
+    eng = NoKLStepEngine(HipOps(), gen.cuda(), X.cuda(), N_BATCH, 1, noise="host", use_graph=False, loss_accum_scale=1.0,
+                         **engine_kw)
     eng.set_epoch_batches(torch.arange(N_BATCH).view(1, -1))
     eng.set_noise(z)
     eng.step()
@@ -170,7 +184,8 @@ def main():
 
     torch.manual_seed(1234)
     use_graph = not args.no_graph
-    eng, data, params = build_engine(rank, world, use_graph)
+    ekw = {"mmd_precision": args.precision} if args.precision else {}
+    eng, data, params = build_engine(rank, world, use_graph, **ekw)
     def prewarm(e):
         t_end, k = time.perf_counter() + args.prewarm_seconds, 0
         while time.perf_counter() < t_end:
@@ -187,7 +202,7 @@ def main():
             raise
         print(f"[bench] HIP-graph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
         use_graph = False
-        eng, data, params = build_engine(rank, world, False)
+        eng, data, params = build_engine(rank, world, False, **ekw)
         prewarm(eng)
         run_steps(eng, args.warmup, 0)
         torch.cuda.synchronize()
@@ -215,33 +230,55 @@ def main():
         out = {
             "metric": "V-GAN train steps/sec (batch=1024, d=784)", "value": steps_per_s, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (MMD products: split-bf16 x3 on the bf16 MFMA, fp32 accumulate)" if eng.bf3 else "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD, "global_batch": N_BATCH, "features": D_FEAT, "latent": eng.L,
                        "rows_per_gpu": eng.nl, "parallelism": f"dp{world} (row-sharded Gram, replicated generator)",
                        "hip_graph": bool(use_graph), "mean_loss": mean_loss, "prewarm_s": args.prewarm_seconds,
-                       "generator": eng.mode},
+                       "generator": eng.mode, "mmd_precision": eng.precision},
         }
-        g = kern["mmd_gram"]
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1:
+        def traffic_of(kernel):
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if not (os.path.exists(tp) and world == 1):
+                return None
             try:
-                traffic = json.load(open(tp)).get("mmd_gram_kernel", {}).get("hbm_bytes_per_launch")
+                return json.load(open(tp)).get(kernel, {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "mmd_gram_kernel<4,false>", "achieved": g["tflops"],
-                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                           "traffic": traffic, "avg_launch_ms": g["ms"], "algorithmic_flop_per_launch": g["flop"],
-                           "also": {"mmd_backward_kernel<4>": {"achieved": kern["mmd_backward"]["tflops"],
-                                                              "frac": kern["mmd_backward"]["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                                                              "avg_launch_ms": kern["mmd_backward"]["ms"]}},
-                           "step_frac": (8.0 * N_BATCH * N_BATCH * D_FEAT + 6.0 * N_BATCH * (eng.fp.total)) * steps_per_s
-                           / world / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+                return None
+
+        step_flop = 8.0 * N_BATCH * N_BATCH * D_FEAT + 6.0 * N_BATCH * eng.fp.total
+        if eng.bf3:
+            # The dominant kernel issues v_mfma_f32_32x32x16_bf16; `achieved` is ALGORITHMIC flops / launch time as the
+            # contract says, `peak` the dense bf16 MFMA rate.  Each algorithmic product costs three bf16 products
+            # (hi.hi' + hi.lo' + lo.hi'), so the executed MFMA rate is 3x `achieved`; both fractions are reported.
+            name, peak = "mmd_gram_bf3_kernel<64>", BF16_MFMA_PEAK_TFLOPS
+            g = kern[name]
+            extra = {"executed_mfma_tflops": 3.0 * g["tflops"], "executed_frac": 3.0 * g["tflops"] / peak,
+                     "vs_fp32_mfma_peak": g["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                     "note": "fp32-accurate Gram on the bf16 MFMA via a 3-way operand split; the fp32-MFMA kernel of the same "
+                             "contraction is listed under 'also' with its own peak (157.3)"}
+        else:
+            name, peak = "mmd_gram_kernel<4,false,1>", FP32_MFMA_PEAK_TFLOPS
+            g = kern[name]
+            extra = {}
+        also = {}
+        for k, v in kern.items():
+            if k == name or "tflops" not in v:
+                continue
+            pk = BF16_MFMA_PEAK_TFLOPS if "bf3" in k else FP32_MFMA_PEAK_TFLOPS
+            also[k] = {"achieved": v["tflops"], "peak": pk, "frac": v["tflops"] / pk, "avg_launch_ms": v["ms"]}
+        if "bf3_prepare_kernel" in kern:
+            also["bf3_prepare_kernel"] = {"avg_launch_ms": kern["bf3_prepare_kernel"]["ms"], "bound": "hbm"}
+        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
+                           "frac": g["tflops"] / peak, "traffic": traffic_of(name.split("<")[0]), "avg_launch_ms": g["ms"],
+                           "algorithmic_flop_per_launch": g["flop"], **extra, "also": also,
+                           "step_tflops": step_flop * steps_per_s / world / 1e12,
+                           "step_frac_of_fp32_mfma_peak": step_flop * steps_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_loss, (X, z) = cpu_baseline(data, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
-            gl = gpu_first_loss(params, X, z)
-            out["parity"] = {"loss_gpu": gl, "loss_cpu_port": cpu_loss, "abs_diff": abs(gl - cpu_loss), "bar": 1e-4}
+            gl = gpu_first_loss(params, X, z, mmd_precision=eng.precision)
+            out["parity"] = {"mmd_precision": eng.precision, "loss_gpu": gl, "loss_cpu_port": cpu_loss, "abs_diff": abs(gl - cpu_loss), "bar": 1e-4}
             out["speedup_vs_cpu"] = steps_per_s / cb["value"]
         print(json.dumps(out), flush=True)
     if dist:

@@ -194,10 +194,12 @@ int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const floa
                       float* partial, const float* S, int lds, int from_softmax, int row_offset,
                       uint64_t* colpart, int nrows, int d, vgan_stream_t stream);
 /* vgan_mmd_backward on the split operands: out = 2 (rowsum(W) z - W . Z) * mul with W = Wh + Wl [nr, kn]
- * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue. */
+ * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue.  splits / slab_stride as in
+ * vgan_mmd_backward (slabs of out, summed by the consumer in slab order). */
 int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh,
                           const uint16_t* ZTl, int kn, int kp, const float* Z, int ldz, int wrow0, int nr,
-                          int p, const float* mul, int ldmul, float* out, int ldo, vgan_stream_t stream);
+                          int p, const float* mul, int ldmul, float* out, int ldo, int splits,
+                          int64_t slab_stride, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

@@ -280,7 +280,9 @@ class CpuOps:
         if S is not None:
             self.colmax_partial(S, row_offset, colpart, from_softmax)
 
-    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out):
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0):
+        for q in range(1, splits):  # the whole product goes to slab 0
+            torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + q * slab_stride).zero_()
         wh, wl, th, tl = self._bf(Wh)[:nr], self._bf(Wl)[:nr], self._bf(ZTh)[:p], self._bf(ZTl)[:p]
         prod = wh @ th.T + wh @ tl.T + wl @ th.T
         z = _np(Z)[wrow0:wrow0 + nr, :p].astype(np.float64)

@@ -289,7 +289,7 @@ def test_c3_step_vs_fp64_reference(ops, mode):
     n, d = 1024, 784
     data = orc.synthetic_dataset("c3", rows=2048)[:n]
     z = np.random.default_rng(5).normal(size=(n, orc.latent_size(d))).astype(np.float32)
-    eng, _ = make_engine(ops, orc.synthetic_generator_params(d), data, n, generator_mode=mode)
+    eng, _ = make_engine(ops, orc.synthetic_generator_params(d), data, n, generator_mode=mode, mmd_precision="fp32")
     eng.set_epoch_batches(torch.arange(n).view(1, n))
     eng.set_noise(torch.as_tensor(z))
     eng.step()
@@ -414,16 +414,18 @@ def test_vgan_kernel_learning_fit_matches_reference_run():
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
 
 
-@pytest.mark.parametrize("n,d,rows", [(500, 166, 1500), (96, 33, 300), (250, 784, 500)])
+@pytest.mark.parametrize("n,d,rows", [(500, 166, 1500), (96, 33, 300), (250, 784, 500), (600, 901, 1250)])
 def test_ragged_shapes_trajectory_vs_oracle(ops, n, d, rows):
     """Default-like batch sizes that are no multiple of the 64-wide tile (the reference's default is 500), feature counts
-    that are no multiple of 4, and an epoch with a dropped remainder: 6 steps against the fp64 oracle."""
+    that are no multiple of 4, and an epoch with a dropped remainder: 6 steps against the fp64 oracle.  The precision
+    mode is the engine's own choice ("auto"): fp32 kernels for the first three shapes, split-bf16 for the last."""
     rng = np.random.default_rng(n + d)
     data = (rng.normal(size=(rows, d)) * rng.uniform(0.5, 2.0, size=(1, d))).astype(np.float32)
     params = orc.synthetic_generator_params(d, seed=3)
     L = orc.latent_size(d)
     nb = rows // n
     eng, _ = make_engine(ops, params, data, n, nb=nb, graph=True)
+    assert eng.precision == ("bf16x3" if 2 * n * d >= (1 << 20) else "fp32")
     ref = orc.NoKLTrainer([p.astype(np.float64) for p in params])
     perm = np.stack([rng.permutation(rows)[:n] for _ in range(nb)])
     eng.set_epoch_batches(torch.as_tensor(perm))
@@ -501,6 +503,10 @@ def test_bf3_prepare_and_kernels_vs_fp64(ops):
     ops.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, n, n, d, None, out)
     dY, _ = orc.mmd_backward(X.astype(np.float64), Y.astype(np.float64), U.astype(np.float64), 0.0, f["bw"])
     np.testing.assert_allclose(host(out), dY, rtol=0, atol=1e-3 * np.abs(dY).max())
+    for splits in (2, 3, 40):  # split-K slabs (40 > K tiles: trailing slabs are empty and must come back zero)
+        slabs = torch.full((splits, n, d), float("nan"), device="cuda")
+        ops.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, n, n, d, None, slabs[0], splits, n * d)
+        np.testing.assert_allclose(host(slabs.sum(0)), host(out), rtol=0, atol=1e-5 * float(out.abs().max()) + 1e-9)
 
 
 @pytest.mark.parametrize("mode", ["collapsed"])

@@ -9,4 +9,4 @@ eng, data, params = bench.build_engine(0, 1, False)
 bench.run_steps(eng, 3, 0)
 torch.cuda.synchronize()
 k = bench.kernel_rooflines(eng)
-print({n: (round(v["ms"] * 1e3, 1), round(v["tflops"], 1)) for n, v in k.items()})
+print({n: (round(v["ms"] * 1e3, 1), round(v.get("tflops", 0.0), 1)) for n, v in k.items()})

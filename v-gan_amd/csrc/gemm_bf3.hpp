@@ -1,0 +1,256 @@
+// Split-bf16 tile main loop shared by the Gram and backward kernels of mmd_bf16.hip (and by tools/ablate_bf3.hip).
+#pragma once
+#include <type_traits>
+
+#include "gemm_core.hpp"
+
+namespace vgan {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // plain vector type: assignable in any address space
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+
+
+// ---- the split-bf16 tile main loop: 64x64 output, 256 threads (2x2 waves), K tile of 64 -----------------------
+// BK = 64: 73,728 B of LDS -> two workgroups per CU; BK = 32: 40,960 B -> three, so that all 528 Gram tiles of the
+// metric's configuration are resident at once (no second round of workgroups on the 16 CUs that are dealt three).
+//
+// KSPLIT (BK = 64 only): the four waves do not split the 64x64 output into quadrants; wave w computes the WHOLE tile for
+// k16 step w of every K tile (4 accumulators) and the partial tiles are summed through LDS once, after the loop, so
+// that each wave ends up with the quadrant it would have owned.  The main loop is bound by the LDS pipe (ablation in
+// profiles/README.md: dropping the MFMAs changes nothing, dropping the LDS stores saves a third): per K tile the quadrant
+// form reads 64 KB of fragments + writes 32 KB, the K-split form reads 32 KB + writes 32 KB.
+template <int BK_, bool KSPLIT = false>
+struct GemmBF3 {
+    static_assert(!KSPLIT || BK_ == 64, "the K split deals the four k16 steps of a 64-wide K tile to the four waves");
+    static constexpr int BK = BK_;                 // bf16 elements of K per tile
+    static constexpr int NR = BK / 32;             // 16-byte pieces per thread and operand part
+    static constexpr int QPR = BK / 8;             // 16-byte pieces per row
+    static constexpr int KS = BK / 16;             // MFMA k steps per tile
+    static constexpr int ROWB = (BK + 8) * 2;      // bytes per LDS row: +16 pad (stride = 36 or 20 dwords = 4 * odd)
+    static constexpr int PART = 64 * ROWB;         // one operand part (64 rows)
+    static constexpr int BUF = 4 * PART;           // Ah | Al | Bh | Bl
+    static constexpr int kLdsBytes = 2 * BUF;      // double buffered
+
+    struct Stage {
+        u32x4 v[4][NR];  // [part][r]
+        const char* src[4][NR];
+        int lofs[NR];
+        __device__ __forceinline__ void init(const unsigned short* Ah, const unsigned short* Al, long lda, int m0, int M,
+                                             const unsigned short* Bh, const unsigned short* Bl, long ldb, int n0, int N, int tid) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int f = tid + kBlock * r, row = f / QPR, q = f % QPR;
+                const long ra = (long)min(m0 + row, M - 1) * lda + 8 * q, rb = (long)min(n0 + row, N - 1) * ldb + 8 * q;
+                src[0][r] = reinterpret_cast<const char*>(Ah + ra);
+                src[1][r] = reinterpret_cast<const char*>(Al + ra);
+                src[2][r] = reinterpret_cast<const char*>(Bh + rb);
+                src[3][r] = reinterpret_cast<const char*>(Bl + rb);
+                lofs[r] = row * ROWB + q * 16;
+            }
+        }
+        __device__ __forceinline__ void load(int k0) {  // K is a multiple of 64 by construction: no k guard
+#pragma unroll
+            for (int part = 0; part < 4; ++part)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) v[part][r] = *reinterpret_cast<const u32x4*>(src[part][r] + 2 * (long)k0);
+        }
+        __device__ __forceinline__ void store(char __attribute__((address_space(3)))* buf) const {
+#pragma unroll
+            for (int part = 0; part < 4; ++part)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) *(lds_u4*)(buf + part * PART + lofs[r]) = v[part][r];
+        }
+        // sum over k of the staged A values (hi + lo) of staged row r
+        __device__ __forceinline__ float a_rowpart(int r) const {
+            float s = 0.f;
+            const unsigned* h = reinterpret_cast<const unsigned*>(&v[0][r]);
+            const unsigned* l = reinterpret_cast<const unsigned*>(&v[1][r]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s += __uint_as_float(h[e] << 16) + __uint_as_float(h[e] & 0xFFFF0000u);
+                s += __uint_as_float(l[e] << 16) + __uint_as_float(l[e] & 0xFFFF0000u);
+            }
+            return s;
+        }
+    };
+
+    // acc (+)= A[m0.., :] . B[n0.., :]^T over K (multiple of 64).  SIDE_A: rs_lds[64] = sum_k A[m0 + m, k].
+    template <bool SIDE_A>
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K,
+                                               char* lds_generic, float* rs_generic, f32x16& acc) {
+        typedef char __attribute__((address_space(3))) lds_c;
+        lds_c* lds = (lds_c*)lds_generic;
+        lds_f* rs_lds = (lds_f*)rs_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        const int fi = lane & 31, fh = lane >> 5;
+        Stage st;
+        st.init(Ah, Al, lda, m0, M, Bh, Bl, ldb, n0, N, tid);
+        float rsum[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rsum[r] = 0.f;
+        auto side = [&]() {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) rsum[r] += st.a_rowpart(r);
+        };
+        const int nk = K / BK;
+        st.load(0);
+        st.store(lds);
+        if constexpr (SIDE_A) side();
+        if (nk > 1) st.load(BK);
+        __syncthreads();
+        f32x16 part[2][2];  // KSPLIT: this wave's partial tile
+        if constexpr (KSPLIT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+        }
+        auto body = [&](int kt, auto store_next, auto load_next2) {
+            const lds_c* buf = lds + (kt & 1) * BUF;
+            if constexpr (KSPLIT) {
+                const lds_c* pa = buf + fi * ROWB + wave * 32 + fh * 16;  // k16 step = wave
+                const lds_c* pb = pa + 2 * PART;
+                u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *(const lds_u4*)(pa + i * 32 * ROWB);
+                    al[i] = *(const lds_u4*)(pa + PART + i * 32 * ROWB);
+                    bh[i] = *(const lds_u4*)(pb + i * 32 * ROWB);
+                    bl[i] = *(const lds_u4*)(pb + PART + i * 32 * ROWB);
+                }
+                if constexpr (decltype(store_next)::value) {
+#ifndef VGAN_ABLATE_NO_LDS_STORE
+                    st.store(lds + ((kt & 1) ^ 1) * BUF);
+#endif
+                    if constexpr (SIDE_A) side();
+                }
+#ifndef VGAN_ABLATE_NO_GLOBAL
+                if constexpr (decltype(load_next2)::value) st.load((kt + 2) * BK);
+#endif
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xl = __builtin_bit_cast(bf16x8, al[i]);
+                        const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[j]), yl = __builtin_bit_cast(bf16x8, bl[j]);
+                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, part[i][j], 0, 0, 0);  // small terms first
+                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, part[i][j], 0, 0, 0);
+                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, part[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_iglp_opt(0);
+#ifndef VGAN_ABLATE_NO_BARRIER
+                __syncthreads();
+#endif
+                return;
+            }
+            const lds_c* pa = buf + (wm0 + fi) * ROWB + fh * 16;
+            const lds_c* pb = buf + 2 * PART + (wn0 + fi) * ROWB + fh * 16;
+            u32x4 ah[KS], al[KS], bh[KS], bl[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {  // k16 step s: this lane's 8 consecutive k = 16 s + 8 fh ..
+                ah[s] = *(const lds_u4*)(pa + s * 32);
+                al[s] = *(const lds_u4*)(pa + PART + s * 32);
+                bh[s] = *(const lds_u4*)(pb + s * 32);
+                bl[s] = *(const lds_u4*)(pb + PART + s * 32);
+            }
+            if constexpr (decltype(store_next)::value) {
+#ifndef VGAN_ABLATE_NO_LDS_STORE
+                st.store(lds + ((kt & 1) ^ 1) * BUF);
+#endif
+                if constexpr (SIDE_A) side();
+            }
+#ifndef VGAN_ABLATE_NO_GLOBAL
+            if constexpr (decltype(load_next2)::value) st.load((kt + 2) * BK);
+#endif
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[s]), xl = __builtin_bit_cast(bf16x8, al[s]);
+                const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[s]), yl = __builtin_bit_cast(bf16x8, bl[s]);
+#ifdef VGAN_ABLATE_NO_MFMA
+                acc[s] += __builtin_bit_cast(f32x4, ah[s] ^ al[s] ^ bh[s] ^ bl[s])[0];
+#else
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);  // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+#ifndef VGAN_ABLATE_ONE_PRODUCT
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+#endif
+#endif
+            }
+            __builtin_amdgcn_iglp_opt(0);
+#ifndef VGAN_ABLATE_NO_BARRIER
+            __syncthreads();
+#endif
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) body(kt, T{}, T{});
+        if (kt + 1 < nk) {
+            body(kt, T{}, F{});
+            ++kt;
+        }
+        body(kt, F{}, F{});
+        if constexpr (KSPLIT) {
+            // the staging buffers are free (the last body ended in a barrier): slot [quadrant q][wave v][g] of 64 x 16 B
+            typedef __attribute__((address_space(3))) f32x4 lds_v4;
+            lds_v4* red = (lds_v4*)lds;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q != wave) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16& src = part[q >> 1][q & 1];
+                        red[((q * 4 + wave) * 4 + g) * 64 + lane] = f32x4{src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
+                    }
+                }
+            __syncthreads();
+            // fixed summation order v = 0..3 (own partial in its place): the result does not depend on which wave sums
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    f32x4 x;
+                    if (v == wave) {
+                        f32x16 own;
+                        own = wave == 0 ? part[0][0] : wave == 1 ? part[0][1] : wave == 2 ? part[1][0] : part[1][1];
+                        x = f32x4{own[4 * g], own[4 * g + 1], own[4 * g + 2], own[4 * g + 3]};
+                    } else {
+                        x = red[((wave * 4 + v) * 4 + g) * 64 + lane];
+                    }
+                    t = v == 0 ? x : t + x;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * g + e] += t[e];
+            }
+            __syncthreads();  // rs_lds / the caller may reuse LDS
+        }
+        if constexpr (SIDE_A) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float s = rsum[r];
+#pragma unroll
+                for (int o = 1; o < QPR; o <<= 1) s += __shfl_xor(s, o, 64);
+                const int f = tid + kBlock * r;
+                if (f % QPR == 0) rs_lds[f / QPR] = s;
+            }
+            __syncthreads();
+        }
+    }
+    __device__ static __forceinline__ int sub_row(int r) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int sub_col() {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave & 1) * 32 + (lane & 31);
+    }
+};
+
+}  // namespace vgan

@@ -12,15 +12,10 @@
 // the transposed copy, for the backward product, whose B fragment needs 8 consecutive k (= Z rows) per lane.
 #include <stdlib.h>
 
-#include "gemm_core.hpp"
+#include "gemm_bf3.hpp"
 #include "mmd_common.hpp"
 
 namespace vgan {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // plain vector type: assignable in any address space
-typedef __attribute__((address_space(3))) u32x4 lds_u4;
-typedef __attribute__((address_space(3))) unsigned short lds_u16;
 
 __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 __device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
@@ -33,173 +28,68 @@ __device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned
 // Zh/Zl [rows_pad, kp]  (kp = features padded to 64, zero filled);  ZTh/ZTl [kp, kn]  (kn = rows padded to 64)
 __global__ __launch_bounds__(kBlock) void bf3_prepare_kernel(const float* __restrict__ Z, int ldz, int rows, int p,
                                                             unsigned short* __restrict__ Zh, unsigned short* __restrict__ Zl, int kp,
-                                                            unsigned short* __restrict__ ZTh, unsigned short* __restrict__ ZTl, int kn) {
-    __shared__ unsigned short th[64][66], tl[64][66];  // [row k][feature j], padded
+                                                            unsigned short* __restrict__ ZTh, unsigned short* __restrict__ ZTl, int kn,
+                                                            int vec) {
+    // one 64 (rows k) x 64 (features j) tile per workgroup; thread t owns the 4x4 patch rows 4*(t/16).., features 4*(t%16)..
+    // so that both images leave as 8-byte (4 x bf16) stores: row-major straight away, transposed after a pass through LDS
+    __shared__ unsigned short th[64][68], tl[64][68];  // [feature j][row k]
     const int j0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // tx: feature within tile, ty: row group
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
-        const int k = k0 + r, j = j0 + tx;
-        const float v = (k < rows && j < p) ? Z[(long)k * ldz + j] : 0.f;
-        unsigned short hi, lo;
-        split_bf16(v, hi, lo);
-        th[r][tx] = hi;
-        tl[r][tx] = lo;
-        if (k < rows) {  // row-major image (rows beyond `rows` do not exist in Zh/Zl)
-            Zh[(long)k * kp + j] = hi;
-            Zl[(long)k * kp + j] = lo;
+    const int tj = 4 * (threadIdx.x & 15), tk = 4 * (threadIdx.x >> 4);
+    unsigned short hi[4][4], lo[4][4];  // [row][feature]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int k = k0 + tk + a;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < rows) {
+            if (vec && j0 + tj + 3 < p) {
+                const float4 q = *reinterpret_cast<const float4*>(Z + (long)k * ldz + j0 + tj);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (j0 + tj + b < p) v[b] = Z[(long)k * ldz + j0 + tj + b];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) split_bf16(v[b], hi[a][b], lo[a][b]);
+        if (k < rows) {  // row-major image (kp is a multiple of 64: the 8-byte store is aligned)
+            *reinterpret_cast<uint2*>(Zh + (long)k * kp + j0 + tj) =
+                make_uint2((unsigned)hi[a][0] | ((unsigned)hi[a][1] << 16), (unsigned)hi[a][2] | ((unsigned)hi[a][3] << 16));
+            *reinterpret_cast<uint2*>(Zl + (long)k * kp + j0 + tj) =
+                make_uint2((unsigned)lo[a][0] | ((unsigned)lo[a][1] << 16), (unsigned)lo[a][2] | ((unsigned)lo[a][3] << 16));
         }
     }
-    __syncthreads();
-    if (ZTh != nullptr) {
-#pragma unroll 4
-        for (int r = ty; r < 64; r += 4) {  // r: feature within tile, tx: row k within tile
-            const long o = (long)(j0 + r) * kn + k0 + tx;
-            ZTh[o] = th[tx][r];
-            ZTl[o] = tl[tx][r];
+    if (ZTh == nullptr) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            th[tj + b][tk + a] = hi[a][b];
+            tl[tj + b][tk + a] = lo[a][b];
         }
+    __syncthreads();
+    // thread t now owns feature rows 4*(t/16).. x 4 consecutive k at 4*(t%16)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int j = tk + a, kk = tj;
+        const long o = (long)(j0 + j) * kn + k0 + kk;
+        *reinterpret_cast<uint2*>(ZTh + o) = make_uint2((unsigned)th[j][kk] | ((unsigned)th[j][kk + 1] << 16),
+                                                        (unsigned)th[j][kk + 2] | ((unsigned)th[j][kk + 3] << 16));
+        *reinterpret_cast<uint2*>(ZTl + o) = make_uint2((unsigned)tl[j][kk] | ((unsigned)tl[j][kk + 1] << 16),
+                                                        (unsigned)tl[j][kk + 2] | ((unsigned)tl[j][kk + 3] << 16));
     }
 }
 
-// ---- the split-bf16 tile main loop: 64x64 output, 256 threads (2x2 waves), K tile of 64 -----------------------
-struct GemmBF3 {
-    static constexpr int BK = 64;                  // bf16 elements of K per tile
-    static constexpr int ROWB = (BK + 8) * 2;      // bytes per LDS row: 128 + 16 pad (stride = 36 dwords = 4 * odd)
-    static constexpr int PART = 64 * ROWB;         // one operand part (64 rows)
-    static constexpr int BUF = 4 * PART;           // Ah | Al | Bh | Bl
-    static constexpr int kLdsBytes = 2 * BUF;      // double buffered: 73,728 B
-
-    struct Stage {
-        u32x4 v[4][2];  // [part][r]
-        const char* src[4][2];
-        int lofs[2];
-        __device__ __forceinline__ void init(const unsigned short* Ah, const unsigned short* Al, long lda, int m0, int M,
-                                             const unsigned short* Bh, const unsigned short* Bl, long ldb, int n0, int N, int tid) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int f = tid + kBlock * r, row = f >> 3, q = f & 7;
-                const long ra = (long)min(m0 + row, M - 1) * lda + 8 * q, rb = (long)min(n0 + row, N - 1) * ldb + 8 * q;
-                src[0][r] = reinterpret_cast<const char*>(Ah + ra);
-                src[1][r] = reinterpret_cast<const char*>(Al + ra);
-                src[2][r] = reinterpret_cast<const char*>(Bh + rb);
-                src[3][r] = reinterpret_cast<const char*>(Bl + rb);
-                lofs[r] = row * ROWB + q * 16;
-            }
-        }
-        __device__ __forceinline__ void load(int k0) {  // K is a multiple of 64 by construction: no k guard
-#pragma unroll
-            for (int part = 0; part < 4; ++part)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) v[part][r] = *reinterpret_cast<const u32x4*>(src[part][r] + 2 * (long)k0);
-        }
-        __device__ __forceinline__ void store(char __attribute__((address_space(3)))* buf) const {
-#pragma unroll
-            for (int part = 0; part < 4; ++part)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) *(lds_u4*)(buf + part * PART + lofs[r]) = v[part][r];
-        }
-        // sum over k of the staged A values (hi + lo) of staged row r
-        __device__ __forceinline__ float a_rowpart(int r) const {
-            float s = 0.f;
-            const unsigned* h = reinterpret_cast<const unsigned*>(&v[0][r]);
-            const unsigned* l = reinterpret_cast<const unsigned*>(&v[1][r]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s += __uint_as_float(h[e] << 16) + __uint_as_float(h[e] & 0xFFFF0000u);
-                s += __uint_as_float(l[e] << 16) + __uint_as_float(l[e] & 0xFFFF0000u);
-            }
-            return s;
-        }
-    };
-
-    // acc (+)= A[m0.., :] . B[n0.., :]^T over K (multiple of 64).  SIDE_A: rs_lds[64] = sum_k A[m0 + m, k].
-    template <bool SIDE_A>
-    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
-                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K,
-                                               char* lds_generic, float* rs_generic, f32x16& acc) {
-        typedef char __attribute__((address_space(3))) lds_c;
-        lds_c* lds = (lds_c*)lds_generic;
-        lds_f* rs_lds = (lds_f*)rs_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-        const int fi = lane & 31, fh = lane >> 5;
-        Stage st;
-        st.init(Ah, Al, lda, m0, M, Bh, Bl, ldb, n0, N, tid);
-        float rsum[2] = {0.f, 0.f};
-        const int nk = K / BK;
-        st.load(0);
-        st.store(lds);
-        if constexpr (SIDE_A) { rsum[0] += st.a_rowpart(0); rsum[1] += st.a_rowpart(1); }
-        if (nk > 1) st.load(BK);
-        __syncthreads();
-        auto body = [&](int kt, auto store_next, auto load_next2) {
-            const lds_c* buf = lds + (kt & 1) * BUF;
-            const lds_c* pa = buf + (wm0 + fi) * ROWB + fh * 16;
-            const lds_c* pb = buf + 2 * PART + (wn0 + fi) * ROWB + fh * 16;
-            u32x4 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {  // k16 step s: this lane's 8 consecutive k = 16 s + 8 fh ..
-                ah[s] = *(const lds_u4*)(pa + s * 32);
-                al[s] = *(const lds_u4*)(pa + PART + s * 32);
-                bh[s] = *(const lds_u4*)(pb + s * 32);
-                bl[s] = *(const lds_u4*)(pb + PART + s * 32);
-            }
-            if constexpr (decltype(store_next)::value) {
-                st.store(lds + ((kt & 1) ^ 1) * BUF);
-                if constexpr (SIDE_A) { rsum[0] += st.a_rowpart(0); rsum[1] += st.a_rowpart(1); }
-            }
-            if constexpr (decltype(load_next2)::value) st.load((kt + 2) * BK);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[s]), xl = __builtin_bit_cast(bf16x8, al[s]);
-                const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[s]), yl = __builtin_bit_cast(bf16x8, bl[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);  // small terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
-            }
-            __builtin_amdgcn_iglp_opt(0);
-            __syncthreads();
-        };
-        using T = std::true_type;
-        using F = std::false_type;
-        int kt = 0;
-        for (; kt + 2 < nk; ++kt) body(kt, T{}, T{});
-        if (kt + 1 < nk) {
-            body(kt, T{}, F{});
-            ++kt;
-        }
-        body(kt, F{}, F{});
-        if constexpr (SIDE_A) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                float s = rsum[r];
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                s += __shfl_xor(s, 4, 64);
-                const int f = tid + kBlock * r;
-                if ((f & 7) == 0) rs_lds[f >> 3] = s;
-            }
-            __syncthreads();
-        }
-    }
-    __device__ static __forceinline__ int sub_row(int r) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        return (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    }
-    __device__ static __forceinline__ int sub_col() {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        return (wave & 1) * 32 + (lane & 31);
-    }
-};
-
 // ---- Gram tile + fused epilogue (see mmd.hip's mmd_gram_kernel; Wg leaves as a hi/lo bf16 pair) ----------------
-__global__ __launch_bounds__(kBlock, 2) void mmd_gram_bf3_kernel(const unsigned short* __restrict__ Zh, const unsigned short* __restrict__ Zl,
+template <int BK>
+__global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_gram_bf3_kernel(const unsigned short* __restrict__ Zh, const unsigned short* __restrict__ Zl,
                                                                 int kp, const float* __restrict__ sq, int n,
                                                                 const float* __restrict__ bw_ptr, const TileDesc* __restrict__ tiles,
                                                                 int ntiles, unsigned short* __restrict__ Wh,
                                                                 unsigned short* __restrict__ Wl, int ldw, int wrow0,
                                                                 float* __restrict__ partial, ColmaxJob cj) {
-    __shared__ __attribute__((aligned(16))) char lds[GemmBF3::kLdsBytes];
+    using G = GemmBF3<BK>;
+    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     __shared__ float red[8];
     if ((int)blockIdx.x >= ntiles) {
         const int cb = blockIdx.x - ntiles;
@@ -210,10 +100,10 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_bf3_kernel(const unsigned 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    GemmBF3::run<false>(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, nullptr, acc);
+    G::template run<false>(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, nullptr, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = td.c0 + GemmBF3::sub_col();
+    const int j = td.c0 + G::sub_col();
     const bool jok = j < td.clim;
     const float sj = sq[min(j, td.clim - 1)];
     const float bw = bw_ptr[0];
@@ -222,10 +112,17 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_bf3_kernel(const unsigned 
     const bool store = (td.flags & VGAN_TF_STORE) && Wh != nullptr;
     const bool mirror = store && (td.flags & VGAN_TF_MIRROR);
     float ksum = 0.f;
-    unsigned short wh[16], wl[16];
+    // The gradient weights leave through LDS (the staging buffers are free: the main loop ended in a barrier), so that
+    // both the direct and the mirrored image go out as 32-byte pieces, four lanes covering one 128-byte row segment,
+    // instead of 2-byte (direct) and row-scattered 8-byte (mirror) stores from the MFMA fragment layout.
+    constexpr int LDT = 72, LDM = 65;  // Wt[i][j]: b128 reads, 4*LDT = 32 mod 64 banks; WtT[j][i]: scalar, odd stride
+    lds_f* Wt = (lds_f*)(float*)lds;
+    lds_f* WtT = Wt + 64 * LDT;
+    static_assert((64 * LDT + 64 * LDM) * 4 <= G::kLdsBytes, "epilogue images must fit the staging buffers");
+    const int lcol = G::sub_col();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int i = td.r0 + GemmBF3::sub_row(r);
+        const int lrow = G::sub_row(r), i = td.r0 + lrow;
         const bool ok = jok && (i < td.rlim);
         const float si = sq[min(i, td.rlim - 1)];
         const float L = fmaxf(si + sj - 2.f * acc[r], 0.f);
@@ -233,33 +130,51 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_bf3_kernel(const unsigned 
         const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
         ksum += ok ? ((t + t2) + (t4 + t8)) + t16 : 0.f;
         const float w = wscale * (((0.25f * t + 0.5f * t2) + (t4 + 2.f * t8)) + 4.f * t16);
-        split_bf16(w, wh[r], wl[r]);
-        if (store && ok) {
-            const long o = (long)(i - wrow0) * ldw + j;
-            Wh[o] = wh[r];
-            Wl[o] = wl[r];
-        }
+        if (store) Wt[lrow * LDT + lcol] = w;
+        if (mirror) WtT[lcol * LDM + lrow] = w;
     }
-    if (mirror && jok) {  // W[j - wrow0, i]: registers 4q..4q+3 are 4 consecutive i -> one 8-byte store per image
-        const int ibase = td.r0 + (wave >> 1) * 32 + 4 * (lane >> 5);
-        const long rowo = (long)(j - wrow0) * ldw;
-        const bool v4 = ((ldw & 3) == 0) && ((td.r0 & 3) == 0);
+    if (store) {  // uniform per workgroup
+        __syncthreads();
+        const int q16 = 16 * (threadIdx.x & 3), line = threadIdx.x >> 2;
+        auto emit = [&](const float (&w)[16], long rowo, int c_first, int c_lim) {
+            unsigned hp[8], lp[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i0 = ibase + 8 * q;
-            if (v4 && i0 + 3 < td.rlim) {
-                *reinterpret_cast<uint2*>(Wh + rowo + i0) =
-                    make_uint2((unsigned)wh[4 * q] | ((unsigned)wh[4 * q + 1] << 16), (unsigned)wh[4 * q + 2] | ((unsigned)wh[4 * q + 3] << 16));
-                *reinterpret_cast<uint2*>(Wl + rowo + i0) =
-                    make_uint2((unsigned)wl[4 * q] | ((unsigned)wl[4 * q + 1] << 16), (unsigned)wl[4 * q + 2] | ((unsigned)wl[4 * q + 3] << 16));
+            for (int e = 0; e < 8; ++e) {
+                unsigned short h0, l0, h1, l1;
+                split_bf16(w[2 * e], h0, l0);
+                split_bf16(w[2 * e + 1], h1, l1);
+                hp[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                lp[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+            if (c_first + 15 < c_lim) {  // ldw % 8 == 0 and tile origins are multiples of 64: 32-byte aligned
+                uint4* dh = reinterpret_cast<uint4*>(Wh + rowo + c_first);
+                uint4* dl = reinterpret_cast<uint4*>(Wl + rowo + c_first);
+                dh[0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                dh[1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+                dl[0] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+                dl[1] = make_uint4(lp[4], lp[5], lp[6], lp[7]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (i0 + e < td.rlim) {
-                        Wh[rowo + i0 + e] = wh[4 * q + e];
-                        Wl[rowo + i0 + e] = wl[4 * q + e];
+                for (int e = 0; e < 16; ++e)
+                    if (c_first + e < c_lim) {
+                        Wh[rowo + c_first + e] = (unsigned short)(hp[e >> 1] >> (16 * (e & 1)));
+                        Wl[rowo + c_first + e] = (unsigned short)(lp[e >> 1] >> (16 * (e & 1)));
                     }
             }
+        };
+        float w[16];
+        if (td.r0 + line < td.rlim) {  // direct image: row i = r0 + line, columns c0 + q16 ..
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 v = *(const lds_f4*)(Wt + line * LDT + q16 + 4 * e);
+                w[4 * e] = v[0]; w[4 * e + 1] = v[1]; w[4 * e + 2] = v[2]; w[4 * e + 3] = v[3];
+            }
+            emit(w, (long)(td.r0 + line - wrow0) * ldw, td.c0 + q16, td.clim);
+        }
+        if (mirror && td.c0 + line < td.clim) {  // mirrored image: row j = c0 + line, columns r0 + q16 ..
+#pragma unroll
+            for (int e = 0; e < 16; ++e) w[e] = WtT[line * LDM + q16 + e];
+            emit(w, (long)(td.c0 + line - wrow0) * ldw, td.r0 + q16, td.rlim);
         }
     }
     ksum = wave_sum(ksum);
@@ -269,13 +184,15 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_gram_bf3_kernel(const unsigned 
 }
 
 // ---- backward: out = 2 (rowsum(W) z - W . Z) * mul, W = Wh + Wl [nr, kn], Z^T = ZTh + ZTl [kp, kn] -------------
-__global__ __launch_bounds__(kBlock, 2) void mmd_backward_bf3_kernel(const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
+template <int BK>
+__global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_kernel(const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                                                     int ldw, const unsigned short* __restrict__ ZTh,
                                                                     const unsigned short* __restrict__ ZTl, int kn,
                                                                     const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                     int ptiles, const float* __restrict__ mul, int ldmul,
-                                                                    float* __restrict__ out, int ldo) {
-    __shared__ __attribute__((aligned(16))) char lds[GemmBF3::kLdsBytes];
+                                                                    float* __restrict__ out, int ldo, int kchunk, long slab_stride) {
+    using G = GemmBF3<BK>;
+    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     __shared__ float rs[64];
     // XCD-aware order as in mmd_backward_kernel: down 4 row panels, then the next feature panel
     const int gx = ptiles, gy = (nr + 63) / 64, total = gx * gy;
@@ -288,14 +205,17 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_backward_bf3_kernel(const unsig
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    GemmBF3::run<true>(Wh, Wl, ldw, ZTh, ZTl, kn, m0, n0, nr, gx * 64, kn, lds, rs, acc);
-    const int col = n0 + GemmBF3::sub_col();
+    // split-K slice blockIdx.y of the row-of-W range (whole K tiles); slab = its share of rowsum and of the product
+    const int k0 = blockIdx.y * kchunk, klen = min(kchunk, kn - k0);
+    out += blockIdx.y * slab_stride;
+    if (klen > 0) G::template run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, gx * 64, klen, lds, rs, acc);
+    const int col = n0 + G::sub_col();
     if (col >= p) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int lrow = GemmBF3::sub_row(r), row = m0 + lrow;
+        const int lrow = G::sub_row(r), row = m0 + lrow;
         if (row < nr) {
-            float v = 2.f * (rs[lrow] * Z[(long)(wrow0 + row) * ldz + col] - acc[r]);
+            float v = klen > 0 ? 2.f * (rs[lrow] * Z[(long)(wrow0 + row) * ldz + col] - acc[r]) : 0.f;
             if (mul != nullptr) v *= mul[(long)row * ldmul + col];
             out[(long)row * ldo + col] = v;
         }
@@ -306,13 +226,23 @@ __global__ __launch_bounds__(kBlock, 2) void mmd_backward_bf3_kernel(const unsig
 
 using namespace vgan;
 
+// K tile of the split-bf16 kernels (measurement knob; see the GemmBF3 comment)
+static int bf3_bk() {
+    static const int v = [] {
+        const char* e = getenv("VGAN_BF3_BK");
+        return (e != nullptr && atoi(e) == 64) ? 64 : 32;
+    }();
+    return v;
+}
+
 extern "C" int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,
                                     uint16_t* ZTl, int kn, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(Z && Zh && Zl && rows > 0 && p > 0 && ldz >= p && kp >= p && kp % 64 == 0);
+    VGAN_CHECK_ARG(Z && Zh && Zl && rows > 0 && p > 0 && ldz >= p && kp >= p && kp % 64 == 0 && aligned16(Zh) && aligned16(Zl));
     VGAN_CHECK_ARG((ZTh == nullptr) == (ZTl == nullptr) && (ZTh == nullptr || (kn >= rows && kn % 64 == 0)));
     dim3 grid(kp / 64, (rows + 63) / 64);
     if (ZTh != nullptr) grid.y = kn / 64;
-    hipLaunchKernelGGL(bf3_prepare_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, rows, p, Zh, Zl, kp, ZTh, ZTl, kn);
+    const int vec = (ldz % 4 == 0) && aligned16(Z);
+    hipLaunchKernelGGL(bf3_prepare_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, rows, p, Zh, Zl, kp, ZTh, ZTl, kn, vec);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -331,22 +261,32 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
         cj = ColmaxJob{S, reinterpret_cast<unsigned long long*>(colpart), lds, row_offset, nrows, d, from_softmax, (d + 63) / 64};
         extra = cj.nbx * ((nrows + kColChunkRows - 1) / kColChunkRows);
     }
-    hipLaunchKernelGGL(mmd_gram_bf3_kernel, dim3(ntiles + extra), dim3(kBlock), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
-                       reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
+    if (bf3_bk() == 64)
+        hipLaunchKernelGGL(mmd_gram_bf3_kernel<64>, dim3(ntiles + extra), dim3(kBlock), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
+                           reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
+    else
+        hipLaunchKernelGGL(mmd_gram_bf3_kernel<32>, dim3(ntiles + extra), dim3(kBlock), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
+                           reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
 
 extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh, const uint16_t* ZTl, int kn,
                                      int kp, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
-                                     float* out, int ldo, vgan_stream_t stream) {
+                                     float* out, int ldo, int splits, int64_t slab_stride, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Wh && Wl && ZTh && ZTl && Z && out && nr > 0 && p > 0 && kn > 0 && kn % 64 == 0 && kp >= p && kp % 64 == 0);
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
     VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(ZTh) && aligned16(ZTl) && ldw % 8 == 0);
+    VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
     const int ptiles = (p + 63) / 64;
-    dim3 grid(ptiles * ((nr + 63) / 64));
-    hipLaunchKernelGGL(mmd_backward_bf3_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0, nr, p,
-                       ptiles, mul, ldmul, out, ldo);
+    const int kchunk = ((kn / 64 + splits - 1) / splits) * 64;
+    dim3 grid(ptiles * ((nr + 63) / 64), splits);
+    if (bf3_bk() == 64)
+        hipLaunchKernelGGL(mmd_backward_bf3_kernel<64>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
+                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride);
+    else
+        hipLaunchKernelGGL(mmd_backward_bf3_kernel<32>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
+                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

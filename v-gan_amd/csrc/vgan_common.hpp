@@ -77,9 +77,15 @@ __device__ __forceinline__ void colmax_partial_body(const float* __restrict__ S,
     const float tau = from_softmax ? 1.0f / (float)d : INFINITY;  // U given directly: no threshold
     unsigned long long best = 0ull;
     if (j < d) {
-        for (int r = r0 + wave; r < min(r0 + kColChunkRows, n); r += NW) {
-            const float sv = S[(long)r * lds + j];
-            const unsigned long long k = colkey_pack(sv < tau ? sv : 1.0f, (unsigned)(row_offset + r));
+        // all loads of the chunk are issued before the first compare (the blocks that run this inside the Gram launch are
+        // latency-bound); rows past the end are clamped to the last row, whose key they merely repeat
+        constexpr int PER = kColChunkRows / NW;
+        float sv[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) sv[e] = S[(long)min(r0 + wave + e * NW, n - 1) * lds + j];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const unsigned long long k = colkey_pack(sv[e] < tau ? sv[e] : 1.0f, (unsigned)(row_offset + min(r0 + wave + e * NW, n - 1)));
             best = k > best ? k : best;
         }
     }

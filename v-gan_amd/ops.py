@@ -221,12 +221,13 @@ class HipOps:
                                               S.stride(0) if S is not None else 0, int(bool(from_softmax)), int(row_offset),
                                               _ptr(colpart), nrows, d, self._stream()), "vgan_mmd_gram_bf3")
 
-    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out):
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0):
         _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         _lib.check(self.lib.vgan_mmd_backward_bf3(_ptr(Wh), _ptr(Wl), Wh.stride(0), _ptr(ZTh), _ptr(ZTl), ZTh.stride(0),
                                                   ZTh.shape[0], _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul,
-                                                  _ptr(out), out.stride(0), self._stream()), "vgan_mmd_backward_bf3")
+                                                  _ptr(out), out.stride(0), int(splits), int(slab_stride), self._stream()),
+                   "vgan_mmd_backward_bf3")
 
     # ---- optimiser / noise / misc ----------------------------------------------------------------
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):

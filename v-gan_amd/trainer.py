@@ -159,21 +159,29 @@ class NoKLStepEngine:
                                   for k in range(1, 5)]
             ops.homogeneous_pack(self.pack_layers, unpack=False)  # once; afterwards Adadelta keeps Wt current
 
+        # "fp32": Gram/backward products on the fp32 MFMA; "bf16x3": split-bf16 operands on the (16x faster) bf16 MFMA,
+        # three products per term, fp32 accumulate (~3e-7 relative on a Gram entry; parity tests hold it to the same
+        # 1e-4 bar).  "auto" keeps fp32 for small problems, where the operand-preparation launch would not pay.
+        self.precision = mmd_precision or os.environ.get("VGAN_MMD_PRECISION", "auto")
+        if self.precision not in ("auto", "fp32", "bf16x3"):
+            raise ValueError(f"mmd_precision must be 'auto', 'fp32' or 'bf16x3', got {self.precision!r}")
+        if self.precision == "auto":
+            self.precision = "bf16x3" if 2 * n * d >= (1 << 20) else "fp32"
+        self.bf3 = self.precision == "bf16x3"
         self.S = torch.zeros(nl, d, **f32)
         self.Z = torch.zeros(2 * n, dp, **f32)
         self.sqn = torch.zeros(2 * n, **f32)
         self.Wg = torch.zeros(nl, 2 * n, **f32)
         # the backward GEMM contracts over the 2n rows of Z; it can be sliced into row slabs that the mask-backward kernel
         # sums (VGAN_BWD_SPLITS), but its 512-thread K-split workgroups already hold four waves per SIMD: default 1
-        self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", "1")))
+        # split-K slabs of the backward product: the split-bf16 kernel is bound by load latency (one 64x64 tile per CU,
+        # 32 dependent K tiles), so two independent K halves per CU pay; the fp32 kernel is MFMA-bound (all counts equal)
+        self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", "2" if self.bf3 else "1")))
         self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
         self.gU = self.gU_slabs[0]
         self.dlogits = torch.zeros(nl, d, **f32)
         # MMD arithmetic: "fp32" (fp32 MFMA, default) or "bf16x3" (split-bf16 operands on the bf16 MFMA, see
         # csrc/mmd_bf16.hip: ~3e-7 relative on a Gram entry at K = 784, a third of the time)
-        self.precision = mmd_precision or os.environ.get("VGAN_MMD_PRECISION", "fp32")
-        if self.precision not in ("fp32", "bf16x3"):
-            raise ValueError(f"mmd_precision must be 'fp32' or 'bf16x3', got {self.precision!r}")
         if self.precision == "bf16x3":
             i16 = dict(dtype=torch.int16, device=self.dev)
             self.kp, self.kn = (d + 63) // 64 * 64, (2 * n + 63) // 64 * 64
@@ -347,8 +355,9 @@ class NoKLStepEngine:
             ops.mmd_finalize_ranks(self.xall, self.world, d, n, self.pen, self.stats, self.colkey, self.loss, self.loss_accum,
                                    self.accum_scale, self.step_counter)
         if bf3:
-            ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU)
-            ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits)
+            ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
+                                 gstride)
+            ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         else:
             ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride)
             ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)

@@ -192,6 +192,7 @@ class VGAN_no_kl(_RunFolder):
         # build-specific knobs (not constructor arguments, so the reference signature is unchanged)
         self.noise_source = "device"   # "device": Philox on the GPU; "host": torch CPU generator (reference CPU-path RNG order)
         self.use_graph = True
+        self.mmd_precision = None      # None: VGAN_MMD_PRECISION or "auto" (see NoKLStepEngine); "fp32" | "bf16x3"
         self.verbose = True
 
     def get_params(self):
@@ -208,7 +209,8 @@ class VGAN_no_kl(_RunFolder):
         rank, world = _dist_info()
         eng = NoKLStepEngine(self._ops(), generator, data, self.batch_size, batches_per_epoch, lr=self.lr,
                              weight_decay=self.weight_decay, penalty_weight=loss_function.weight, seed=self.seed or 0,
-                             noise=self.noise_source, rank=rank, world=world, use_graph=self.use_graph)
+                             noise=self.noise_source, rank=rank, world=world, use_graph=self.use_graph,
+                             mmd_precision=self.mmd_precision)
         shared = loss_function.kernel.bandwidth  # the process-wide RBF may already be calibrated (reference quirk)
         if shared is not None:
             eng.set_bandwidth(float(shared))
