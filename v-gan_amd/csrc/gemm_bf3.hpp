@@ -13,8 +13,9 @@ typedef __attribute__((address_space(3))) unsigned short lds_u16;
 
 
 // ---- the split-bf16 tile main loop: 64x64 output, 256 threads (2x2 waves), K tile of 64 -----------------------
-// BK = 64: 73,728 B of LDS -> two workgroups per CU; BK = 32: 40,960 B -> three, so that all 528 Gram tiles of the
-// metric's configuration are resident at once (no second round of workgroups on the 16 CUs that are dealt three).
+// BK = 64: 73,728 B of LDS -> two workgroups per CU (the default).  BK = 32: 40,960 B -> three per CU, so that all 528
+// Gram tiles of the metric's configuration are resident at once -- measured SLOWER (28.3 vs 25.5 us; the CUs that are
+// dealt three tiles are throughput-bound, not waiting for a second round), kept behind VGAN_BF3_BK=32 for measurement.
 //
 // KSPLIT (BK = 64 only): the four waves do not split the 64x64 output into quadrants; wave w computes the WHOLE tile for
 // k16 step w of every K tile (4 accumulators) and the partial tiles are summed through LDS once, after the loop, so

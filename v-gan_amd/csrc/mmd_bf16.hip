@@ -230,7 +230,7 @@ using namespace vgan;
 static int bf3_bk() {
     static const int v = [] {
         const char* e = getenv("VGAN_BF3_BK");
-        return (e != nullptr && atoi(e) == 64) ? 64 : 32;
+        return (e != nullptr && atoi(e) == 32) ? 32 : 64;  // 64 measured faster (Gram 25.5 vs 28.3 us, backward 24.3 vs 35.8)
     }();
     return v;
 }
