@@ -162,6 +162,22 @@ int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int ntiles, co
                       int chunks, uint64_t* colkey, int n, int d, float weight, double* stats,
                       float* loss, float* loss_accum, float accum_scale, uint64_t* step_counter,
                       vgan_stream_t stream);
+/* The same step tail as a job that rides in a backward launch (vgan_mmd_backward / vgan_mmd_backward_bf3,
+ * argument `finalize`, NULL = none): ONE extra workgroup of that launch does what vgan_mmd_finalize does, off
+ * the critical path (its outputs -- colkey, the loss bookkeeping -- are first needed by the kernel AFTER the
+ * backward product).  Field meaning as the arguments of vgan_mmd_finalize. */
+typedef struct vgan_finalize_job {
+    const float* partial;
+    const int32_t* tiles;
+    const uint64_t* colpart;
+    uint64_t* colkey;
+    double* stats;
+    float* loss;
+    float* loss_accum;
+    uint64_t* step_counter;
+    int32_t ntiles, chunks, n, d;
+    float weight, accum_scale;
+} vgan_finalize_job;
 /* Data-parallel step tail.  gathered: `world` records of 4 + d 64-bit words, record r = rank r's
  * {stats[4] as f64 bits, colkey[d]} (what one all-gather delivers).  Sums the statistics in rank order,
  * takes the per-column maximum of the keys, writes stats / colkey and finishes the loss as vgan_mmd_loss does. */
@@ -176,7 +192,8 @@ int vgan_mmd_finalize_ranks(const uint64_t* gathered, int world, int d, int n, f
  * the slabs (vgan_mask_backward does, or vgan_reduce_slabs). */
 int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr,
                       int ncols, int p, const float* mul, int ldmul, float* out, int ldo,
-                      int splits, int64_t slab_stride, vgan_stream_t stream);
+                      int splits, int64_t slab_stride, const vgan_finalize_job* finalize,
+                      vgan_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * Split-bf16 ("bf16x3") variants of the two dense contractions, for large problems (opt-in precision
  * mode): every operand z = hi + lo with hi = bf16(z), lo = bf16(z - hi), products hi.hi' + hi.lo' + lo.hi'
@@ -199,7 +216,7 @@ int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const floa
 int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh,
                           const uint16_t* ZTl, int kn, int kp, const float* Z, int ldz, int wrow0, int nr,
                           int p, const float* mul, int ldmul, float* out, int ldo, int splits,
-                          int64_t slab_stride, vgan_stream_t stream);
+                          int64_t slab_stride, const vgan_finalize_job* finalize, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

@@ -134,6 +134,9 @@ class CpuOps:
             colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
         self.mmd_loss(stats, colkey if colpart is not None else None, n, d, weight, loss, loss_accum, accum_scale, step_counter)
 
+    def finalize_job(self, *args, **kw):
+        return (args, kw)
+
     def mmd_finalize_ranks(self, gathered, world, d, n, weight, stats, colkey, loss, loss_accum=None, accum_scale=1.0,
                            step_counter=None):
         g = gathered.reshape(world, 4 + d)
@@ -219,7 +222,9 @@ class CpuOps:
         if step_counter is not None:
             step_counter += 1
 
-    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0):
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0, finalize=None):
+        if finalize is not None:
+            self.mmd_finalize(*finalize[0], **finalize[1])
         kchunk = ((ncols + splits - 1) // splits + 31) // 32 * 32
         for sl in range(splits):
             lo, hi = min(sl * kchunk, ncols), min((sl + 1) * kchunk, ncols)
@@ -280,7 +285,9 @@ class CpuOps:
         if S is not None:
             self.colmax_partial(S, row_offset, colpart, from_softmax)
 
-    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0):
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None):
+        if finalize is not None:
+            self.mmd_finalize(*finalize[0], **finalize[1])
         for q in range(1, splits):  # the whole product goes to slab 0
             torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + q * slab_stride).zero_()
         wh, wl, th, tl = self._bf(Wh)[:nr], self._bf(Wl)[:nr], self._bf(ZTh)[:p], self._bf(ZTl)[:p]

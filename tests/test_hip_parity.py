@@ -546,3 +546,55 @@ def test_trajectory_c2_like_bf16x3_vs_oracle(ops):
         assert abs(float(eng.loss) - want["loss"]) < 1e-4, (t, float(eng.loss), want["loss"])
     for i in range(8):
         np.testing.assert_allclose(host(eng.fp.view(eng.fp.flat, i)), ref.params[i], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("bf3", [False, True])
+def test_finalize_job_riding_in_backward_equals_standalone_finalize(ops, bf3):
+    """vgan_finalize_job: the step tail executed by the surplus workgroup of a backward launch writes exactly what
+    vgan_mmd_finalize writes (stats, column keys, loss, accumulators), and the backward product is unchanged."""
+    n, d = 320, 200
+    rng = np.random.default_rng(17)
+    X = rng.normal(size=(n, d)).astype(np.float32)
+    Y = (X * rng.uniform(0.2, 1.0, size=(n, d))).astype(np.float32)
+    S = rng.uniform(0.0, 2.0 / d, size=(n, d)).astype(np.float32)
+    Z = torch.zeros(2 * n, d, device="cuda")
+    Z[:n], Z[n:] = dev(X), dev(Y)
+    sq = torch.empty(2 * n, device="cuda")
+    ops.row_sqnorm(Z, sq, d)
+    tiles = ops.build_tiles(n, 1)
+    bw = torch.full((1,), 37.0, device="cuda")
+    partial = torch.empty(tiles.shape[0], 4, device="cuda")
+    chunks = ops.colmax_chunks(n)
+    colpart = torch.empty(chunks * d, dtype=torch.int64, device="cuda")
+    if bf3:
+        kp, kn = (d + 63) // 64 * 64, (2 * n + 63) // 64 * 64
+        i16 = dict(dtype=torch.int16, device="cuda")
+        Zh, Zl = torch.zeros(2 * n, kp, **i16), torch.zeros(2 * n, kp, **i16)
+        ZTh, ZTl = torch.zeros(kp, kn, **i16), torch.zeros(kp, kn, **i16)
+        Wh, Wl = torch.zeros(n, kn, **i16), torch.zeros(n, kn, **i16)
+        ops.mmd_bf3_prepare(Z, 2 * n, d, Zh, Zl, ZTh, ZTl)
+        ops.mmd_gram_bf3(Zh, Zl, sq, n, bw, tiles, Wh, Wl, n, partial, dev(S), 0, colpart, True)
+    else:
+        Wg = torch.zeros(n, 2 * n, device="cuda")
+        ops.mmd_gram_colmax(Z, sq, n, d, bw, tiles, Wg, n, partial, dev(S), 0, colpart, True)
+
+    def outputs():
+        return dict(colkey=torch.zeros(d, dtype=torch.int64, device="cuda"), stats=torch.zeros(4, dtype=torch.float64, device="cuda"),
+                    loss=torch.zeros(1, device="cuda"), accum=torch.full((1,), 0.5, device="cuda"),
+                    counter=torch.full((1,), 41, dtype=torch.int64, device="cuda"), out=torch.zeros(2, n, d, device="cuda"))
+
+    def backward(o, job):
+        if bf3:
+            ops.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, n, n, d, None, o["out"][0], 2, n * d, job)
+        else:
+            ops.mmd_backward(Wg, Z, n, n, 2 * n, d, None, o["out"][0], 2, n * d, job)
+
+    a, b = outputs(), outputs()
+    ops.mmd_finalize(partial, tiles, colpart, chunks, a["colkey"], n, d, 10.0, a["stats"], a["loss"], a["accum"], 0.25, a["counter"])
+    backward(a, None)
+    job = ops.finalize_job(partial, tiles, colpart, chunks, b["colkey"], n, d, 10.0, b["stats"], b["loss"], b["accum"], 0.25, b["counter"])
+    backward(b, job)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["counter"]) == 42 and float(a["loss"]) != 0.0

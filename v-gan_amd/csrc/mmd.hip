@@ -171,52 +171,7 @@ __global__ void mmd_loss_kernel(const double* __restrict__ stats, const unsigned
 
 // ---- single-GPU step tail in ONE launch: per-tile partials -> block statistics, column chunk keys -> arg-max keys,
 // then the loss (replaces mmd_reduce + colmax_final + mmd_loss, three latency-bound launches).
-__global__ __launch_bounds__(1024) void mmd_finalize_kernel(const float* __restrict__ partial, const TileDesc* __restrict__ tiles,
-                                                           int ntiles, const unsigned long long* __restrict__ colpart, int chunks,
-                                                           unsigned long long* __restrict__ colkey, int n, int d, float weight,
-                                                           double* __restrict__ stats, float* __restrict__ loss,
-                                                           float* __restrict__ loss_accum, float accum_scale,
-                                                           unsigned long long* __restrict__ step_counter) {
-    __shared__ double red[16][5];
-    double s[5] = {0, 0, 0, 0, 0};  // Sxx, Sxy, Syy, sumL, penalty
-    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
-        const int fl = tiles[t].flags;
-        const double w = (fl & VGAN_TF_TWICE) ? 2.0 : 1.0;
-        const float4 pv = reinterpret_cast<const float4*>(partial)[t];
-        s[fl & VGAN_TF_SLOT_MASK] += w * (double)pv.x;
-        s[3] += (((fl & VGAN_TF_SLOT_MASK) == 1) ? 2.0 : w) * (double)pv.y;
-    }
-    if (colpart != nullptr) {
-        for (int j = threadIdx.x; j < d; j += blockDim.x) {
-            unsigned long long b = 0ull;
-            for (int c = 0; c < chunks; ++c) {
-                const unsigned long long k = colpart[(long)c * d + j];
-                b = k > b ? k : b;
-            }
-            colkey[j] = b;
-            s[4] += 1.0 - (double)colkey_value(b);
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        s[q] = wave_sum(s[q]);
-        if (lane == 0) red[wave][q] = s[q];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t[5] = {0, 0, 0, 0, 0};
-        const int nw = blockDim.x >> 6;
-        for (int w = 0; w < nw; ++w)
-            for (int q = 0; q < 5; ++q) t[q] += red[w][q];
-        for (int q = 0; q < 4; ++q) stats[q] = t[q];
-        const double nn = (double)n * (double)n;
-        const double v = (t[0] - 2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
-        loss[0] = (float)v;
-        if (loss_accum) loss_accum[0] += (float)(v * (double)accum_scale);
-        if (step_counter) step_counter[0] += 1ull;
-    }
-}
+__global__ __launch_bounds__(1024) void mmd_finalize_kernel(vgan_finalize_job job) { finalize_body(job); }
 
 // ---- data-parallel step tail: every rank contributes one record {Sxx, Sxy, Syy, sumL (f64 bits) | colkey[d]} of
 // 4 + d 64-bit words (ONE all-gather instead of an all-reduce(SUM) plus an all-reduce(MAX)); this kernel folds the
@@ -262,7 +217,7 @@ template <int VEC, int KW>
 __global__ __launch_bounds__(kBlock * KW, 2) void mmd_backward_kernel(const float* __restrict__ Wg, int ldw, const float* __restrict__ Z,
                                                                 int ldz, int wrow0, int nr, int ncols, int p,
                                                                 const float* __restrict__ mul, int ldmul, float* __restrict__ out,
-                                                                int ldo, int kchunk, long slab_stride) {
+                                                                int ldo, int kchunk, long slab_stride, vgan_finalize_job job) {
     using G = GemmTile<GT, GT, GBK * KW, KC, MC, VEC, 0, KW>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float rs[GT];
@@ -270,6 +225,10 @@ __global__ __launch_bounds__(kBlock * KW, 2) void mmd_backward_kernel(const floa
     // traversal that goes down 4 row panels, then to the next column panel, so the tiles resident on one
     // XCD share their Wg row panels and Z column panels in its private L2.
     const int gx = (p + GT - 1) / GT, gy = (nr + GT - 1) / GT, total = gx * gy;
+    if ((int)blockIdx.x >= total) {  // the one surplus workgroup column of the launch: the step tail (see vgan_finalize_job)
+        if (blockIdx.y == 0) finalize_body(job);
+        return;
+    }
     const int xcd = blockIdx.x % 8, kidx = blockIdx.x / 8;
     const int q = total / 8, r = total % 8;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kidx;
@@ -510,12 +469,10 @@ extern "C" int vgan_mmd_loss(const double* stats, const uint64_t* colkey, int n,
 extern "C" int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int ntiles, const uint64_t* colpart, int chunks,
                                  uint64_t* colkey, int n, int d, float weight, double* stats, float* loss, float* loss_accum,
                                  float accum_scale, uint64_t* step_counter, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(partial && tiles && ntiles > 0 && stats && loss && n > 0 && d > 0);
-    VGAN_CHECK_ARG(colpart == nullptr || (colkey != nullptr && chunks > 0));
-    hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial,
-                       reinterpret_cast<const TileDesc*>(tiles), ntiles, reinterpret_cast<const unsigned long long*>(colpart), chunks,
-                       reinterpret_cast<unsigned long long*>(colkey), n, d, weight, stats, loss, loss_accum, accum_scale,
-                       reinterpret_cast<unsigned long long*>(step_counter));
+    const vgan_finalize_job job{partial, tiles, colpart, colkey, stats, loss, loss_accum, step_counter, ntiles, chunks, n, d, weight,
+                                accum_scale};
+    VGAN_CHECK_ARG(finalize_job_ok(job));
+    hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, job);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -534,7 +491,7 @@ extern "C" int vgan_mmd_finalize_ranks(const uint64_t* gathered, int world, int 
 
 extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr, int ncols, int p,
                                  const float* mul, int ldmul, float* out, int ldo, int splits, int64_t slab_stride,
-                                 vgan_stream_t stream) {
+                                 const vgan_finalize_job* finalize, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Wg && Z && out && nr > 0 && ncols > 0 && p > 0 && ldw >= ncols && ldz >= p && ldo >= p && wrow0 >= 0 &&
                    wrow0 + nr <= ncols);
     VGAN_CHECK_ARG(mul == nullptr || ldmul >= p);
@@ -544,8 +501,13 @@ extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int l
     const int kw = bwd_kw();
     const int kt = GBK * kw;
     const int kchunk = ((ncols + splits - 1) / splits + kt - 1) / kt * kt;  // whole K tiles per slice (keeps 16-byte alignment)
-    dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT), splits), block(kBlock * kw);
-#define VGAN_BWD(V, W) hipLaunchKernelGGL((mmd_backward_kernel<V, W>), grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo, kchunk, (long)slab_stride)
+    vgan_finalize_job job{};
+    if (finalize != nullptr) {
+        VGAN_CHECK_ARG(finalize_job_ok(*finalize));
+        job = *finalize;
+    }
+    dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT) + (finalize != nullptr ? 1 : 0), splits), block(kBlock * kw);
+#define VGAN_BWD(V, W) hipLaunchKernelGGL((mmd_backward_kernel<V, W>), grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo, kchunk, (long)slab_stride, job)
     if (kw == 2) { if (vec) VGAN_BWD(4, 2); else VGAN_BWD(1, 2); }
     else { if (vec) VGAN_BWD(4, 1); else VGAN_BWD(1, 1); }
 #undef VGAN_BWD

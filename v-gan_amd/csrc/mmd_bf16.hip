@@ -190,12 +190,17 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
                                                                     const unsigned short* __restrict__ ZTl, int kn,
                                                                     const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                     int ptiles, const float* __restrict__ mul, int ldmul,
-                                                                    float* __restrict__ out, int ldo, int kchunk, long slab_stride) {
+                                                                    float* __restrict__ out, int ldo, int kchunk, long slab_stride,
+                                                                    vgan_finalize_job job) {
     using G = GemmBF3<BK>;
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     __shared__ float rs[64];
     // XCD-aware order as in mmd_backward_kernel: down 4 row panels, then the next feature panel
     const int gx = ptiles, gy = (nr + 63) / 64, total = gx * gy;
+    if ((int)blockIdx.x >= total) {  // the one surplus workgroup column of the launch: the step tail (see vgan_finalize_job)
+        if (blockIdx.y == 0) finalize_body(job);
+        return;
+    }
     const int xcd = blockIdx.x % 8, kidx = blockIdx.x / 8;
     const int q = total / 8, r8 = total % 8;
     const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + kidx;
@@ -273,20 +278,26 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
 
 extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh, const uint16_t* ZTl, int kn,
                                      int kp, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
-                                     float* out, int ldo, int splits, int64_t slab_stride, vgan_stream_t stream) {
+                                     float* out, int ldo, int splits, int64_t slab_stride, const vgan_finalize_job* finalize,
+                                     vgan_stream_t stream) {
     VGAN_CHECK_ARG(Wh && Wl && ZTh && ZTl && Z && out && nr > 0 && p > 0 && kn > 0 && kn % 64 == 0 && kp >= p && kp % 64 == 0);
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
     VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(ZTh) && aligned16(ZTl) && ldw % 8 == 0);
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
     const int ptiles = (p + 63) / 64;
     const int kchunk = ((kn / 64 + splits - 1) / splits) * 64;
-    dim3 grid(ptiles * ((nr + 63) / 64), splits);
+    vgan_finalize_job job{};
+    if (finalize != nullptr) {
+        VGAN_CHECK_ARG(finalize_job_ok(*finalize));
+        job = *finalize;
+    }
+    dim3 grid(ptiles * ((nr + 63) / 64) + (finalize != nullptr ? 1 : 0), splits);
     if (bf3_bk() == 64)
         hipLaunchKernelGGL(mmd_backward_bf3_kernel<64>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride);
+                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride, job);
     else
         hipLaunchKernelGGL(mmd_backward_bf3_kernel<32>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride);
+                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride, job);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

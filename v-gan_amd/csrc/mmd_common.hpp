@@ -18,4 +18,69 @@ struct ColmaxJob {
     int lds, row_offset, n, d, from_softmax, nbx;  // nbx = ceil(d / 64); job is empty when S == nullptr
 };
 
+
+// The single-rank step tail (vgan_mmd_finalize): partial[] -> stats[4]; colpart[chunks * d] -> colkey[d]; loss and its
+// bookkeeping.  Runs in one workgroup of any size up to 1024 threads: stand-alone (mmd_finalize_kernel) or as the
+// surplus workgroup of a backward launch.
+__device__ __forceinline__ void finalize_body(const vgan_finalize_job& job) {
+    const float* __restrict__ partial = job.partial;
+    const TileDesc* __restrict__ tiles = reinterpret_cast<const TileDesc*>(job.tiles);
+    const unsigned long long* __restrict__ colpart = reinterpret_cast<const unsigned long long*>(job.colpart);
+    unsigned long long* __restrict__ colkey = reinterpret_cast<unsigned long long*>(job.colkey);
+    double* __restrict__ stats = job.stats;
+    float* __restrict__ loss = job.loss;
+    float* __restrict__ loss_accum = job.loss_accum;
+    unsigned long long* __restrict__ step_counter = reinterpret_cast<unsigned long long*>(job.step_counter);
+    const int ntiles = job.ntiles, chunks = job.chunks, n = job.n, d = job.d;
+    const float weight = job.weight, accum_scale = job.accum_scale;
+
+    __shared__ double red[16][5];  // up to 1024 threads
+    double s[5] = {0, 0, 0, 0, 0};  // Sxx, Sxy, Syy, sumL, penalty
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        const int fl = tiles[t].flags;
+        const double w = (fl & VGAN_TF_TWICE) ? 2.0 : 1.0;
+        const float4 pv = reinterpret_cast<const float4*>(partial)[t];
+        s[fl & VGAN_TF_SLOT_MASK] += w * (double)pv.x;
+        s[3] += (((fl & VGAN_TF_SLOT_MASK) == 1) ? 2.0 : w) * (double)pv.y;
+    }
+    if (colpart != nullptr) {
+        for (int j = threadIdx.x; j < d; j += blockDim.x) {
+            unsigned long long b = 0ull;
+            for (int c0 = 0; c0 < chunks; c0 += 16) {  // 16 independent loads in flight (this block is latency-bound)
+                unsigned long long k[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) k[e] = colpart[(long)min(c0 + e, chunks - 1) * d + j];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) b = k[e] > b ? k[e] : b;
+            }
+            colkey[j] = b;
+            s[4] += 1.0 - (double)colkey_value(b);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        s[q] = wave_sum(s[q]);
+        if (lane == 0) red[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[5] = {0, 0, 0, 0, 0};
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w)
+            for (int q = 0; q < 5; ++q) t[q] += red[w][q];
+        for (int q = 0; q < 4; ++q) stats[q] = t[q];
+        const double nn = (double)n * (double)n;
+        const double v = (t[0] - 2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
+        loss[0] = (float)v;
+        if (loss_accum) loss_accum[0] += (float)(v * (double)accum_scale);
+        if (step_counter) step_counter[0] += 1ull;
+    }
+}
+
+inline bool finalize_job_ok(const vgan_finalize_job& j) {
+    return j.partial && j.tiles && j.ntiles > 0 && j.stats && j.loss && j.n > 0 && j.d > 0 &&
+           (j.colpart == nullptr || (j.colkey != nullptr && j.chunks > 0));
+}
+
 }  // namespace vgan

@@ -12,6 +12,13 @@ _f = ctypes.c_float
 _i64 = ctypes.c_int64
 _u64 = ctypes.c_uint64
 
+class FinalizeJob(ctypes.Structure):
+    """struct vgan_finalize_job (include/vgan_hip.h): the step tail riding in a backward launch."""
+    _fields_ = [("partial", _p), ("tiles", _p), ("colpart", _p), ("colkey", _p), ("stats", _p), ("loss", _p), ("loss_accum", _p),
+                ("step_counter", _p), ("ntiles", ctypes.c_int32), ("chunks", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("d", ctypes.c_int32), ("weight", _f), ("accum_scale", _f)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/vgan_hip.h
 SIGNATURES = {
     "vgan_abi_version": (_i, []),
@@ -36,10 +43,10 @@ SIGNATURES = {
     "vgan_mmd_set_bandwidth": (_i, [_p, _i, _p, _p]),
     "vgan_mmd_loss": (_i, [_p, _p, _i, _i, _f, _p, _p, _f, _p, _p]),
     "vgan_mmd_finalize_ranks": (_i, [_p, _i, _i, _i, _f, _p, _p, _p, _p, _f, _p, _p]),
-    "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p]),
+    "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p, _p]),
     "vgan_mmd_bf3_prepare": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
-    "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p]),
+    "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p, _p]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_noise_normal": (_i, [_p, _i, _i, _i, _i, _u64, _p, _u64, _p]),

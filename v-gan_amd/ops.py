@@ -143,6 +143,13 @@ class HipOps:
                                               int(n), int(d), float(weight), _ptr(stats), _ptr(loss), _ptr(loss_accum),
                                               float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_finalize")
 
+    def finalize_job(self, partial, tiles, colpart, chunks, colkey, n, d, weight, stats, loss, loss_accum=None, accum_scale=1.0,
+                     step_counter=None):
+        """The arguments of mmd_finalize as a job for mmd_backward / mmd_backward_bf3 (`finalize=`).  The job holds raw device
+        pointers: the tensors must outlive every launch (and graph replay) that uses it."""
+        return _lib.FinalizeJob(_ptr(partial), _ptr(tiles), _ptr(colpart), _ptr(colkey), _ptr(stats), _ptr(loss), _ptr(loss_accum),
+                                _ptr(step_counter), tiles.shape[0], int(chunks), int(n), int(d), float(weight), float(accum_scale))
+
     def mmd_finalize_ranks(self, gathered, world, d, n, weight, stats, colkey, loss, loss_accum=None, accum_scale=1.0,
                            step_counter=None):
         assert gathered.dtype == torch.int64 and gathered.numel() >= world * (4 + d)
@@ -195,13 +202,15 @@ class HipOps:
         _lib.check(self.lib.vgan_mmd_loss(_ptr(stats), _ptr(colkey), int(n), int(d), float(weight), _ptr(loss), _ptr(loss_accum),
                                           float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_loss")
 
-    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0):
-        """splits > 1: `out` is slab 0 of `splits` partial slabs `slab_stride` elements apart."""
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0, finalize=None):
+        """splits > 1: `out` is slab 0 of `splits` partial slabs `slab_stride` elements apart.  finalize: a finalize_job()
+        that one extra workgroup of the launch executes."""
         _mat(Wg, "Wg"), _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         _lib.check(self.lib.vgan_mmd_backward(_ptr(Wg), Wg.stride(0), _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(ncols), int(p),
                                               _ptr(mul), ldmul, _ptr(out), out.stride(0), int(splits), int(slab_stride),
-                                              self._stream()), "vgan_mmd_backward")
+                                              ctypes.byref(finalize) if finalize is not None else None, self._stream()),
+                   "vgan_mmd_backward")
 
     # ---- split-bf16 MMD (opt-in precision mode) ------------------------------------------------------
     def mmd_bf3_prepare(self, Z, rows, p, Zh, Zl, ZTh=None, ZTl=None):
@@ -221,12 +230,13 @@ class HipOps:
                                               S.stride(0) if S is not None else 0, int(bool(from_softmax)), int(row_offset),
                                               _ptr(colpart), nrows, d, self._stream()), "vgan_mmd_gram_bf3")
 
-    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0):
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None):
         _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         _lib.check(self.lib.vgan_mmd_backward_bf3(_ptr(Wh), _ptr(Wl), Wh.stride(0), _ptr(ZTh), _ptr(ZTl), ZTh.stride(0),
                                                   ZTh.shape[0], _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul,
-                                                  _ptr(out), out.stride(0), int(splits), int(slab_stride), self._stream()),
+                                                  _ptr(out), out.stride(0), int(splits), int(slab_stride),
+                                                  ctypes.byref(finalize) if finalize is not None else None, self._stream()),
                    "vgan_mmd_backward_bf3")
 
     # ---- optimiser / noise / misc ----------------------------------------------------------------

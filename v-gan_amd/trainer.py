@@ -168,6 +168,7 @@ class NoKLStepEngine:
         if self.precision == "auto":
             self.precision = "bf16x3" if 2 * n * d >= (1 << 20) else "fp32"
         self.bf3 = self.precision == "bf16x3"
+        self._fin = None  # finalize job (raw pointers of the tensors below), built at first use
         self.S = torch.zeros(nl, d, **f32)
         self.Z = torch.zeros(2 * n, dp, **f32)
         self.sqn = torch.zeros(2 * n, **f32)
@@ -332,6 +333,7 @@ class NoKLStepEngine:
         ops, n, nl, lo, d = self.ops, self.n, self.nl, self.lo, self.d
         dist = self._collect() if self.exchange else None
         gstride = nl * self.dp
+        fin = None
         bf3 = self.precision == "bf16x3"
         if bf3:
             ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
@@ -342,8 +344,12 @@ class NoKLStepEngine:
             else:
                 ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, lo,
                                     self.colpart, True)
-            ops.mmd_finalize(self.partial, self.tiles, self.colpart, ops.colmax_chunks(nl), self.colkey, n, d, self.pen, self.stats,
-                             self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+            # the step tail (block sums -> stats, column keys, loss bookkeeping) rides in the backward launch as one extra
+            # workgroup: its outputs are first needed by the mask backward, so it leaves the critical path
+            if self._fin is None:
+                self._fin = ops.finalize_job(self.partial, self.tiles, self.colpart, ops.colmax_chunks(nl), self.colkey, n, d, self.pen,
+                                             self.stats, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+            fin = self._fin
         else:
             ops.colmax(self.S, lo, self.colpart, self.xkeys, True)
             if bf3:
@@ -356,10 +362,10 @@ class NoKLStepEngine:
                                    self.accum_scale, self.step_counter)
         if bf3:
             ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
-                                 gstride)
+                                 gstride, fin)
             ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         else:
-            ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride)
+            ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride, fin)
             ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         self._generator_backward_update(dist)
 
