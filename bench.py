@@ -27,7 +27,12 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-N_BATCH, D_FEAT, EPOCH_BATCHES = 1024, 784, 16
+N_BATCH, D_FEAT, EPOCH_BATCHES, CONFIG = 1024, 784, 16, "c3"
+WORKLOADS = {  # --workload: the metric is quoted on c3; c4 / c5 are the larger BASELINE.json configurations (extra lines)
+    "c3": (1024, 784, 16, "configs[2]: MNIST-pixels-as-features stand-in, d=784, batch=1024 (VGAN_no_kl step)"),
+    "c4": (4096, 2048, 4, "configs[3]: synthetic tabular, d=2048, batch=4096 (VGAN_no_kl step)"),
+    "c5": (8192, 4096, 4, "configs[4]: synthetic tabular, d=4096, batch=8192, 5-bandwidth RBF (VGAN_no_kl step)"),
+}
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 WORKLOAD = "configs[2]: MNIST-pixels-as-features stand-in, d=784, batch=1024 (VGAN_no_kl step)"
@@ -41,6 +46,7 @@ def parse():
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed steps run right after graph capture so that the GPU clock has ramped (DVFS) before the "
                          "W warm-up steps; a fit runs for minutes, so the ramped state is the representative one")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3"], default=None,
@@ -54,7 +60,7 @@ def build_engine(rank, world, use_graph, **engine_kw):
     from vgan_amd import synth
     from vgan_amd.ops import HipOps
     from vgan_amd.trainer import NoKLStepEngine
-    data = synth.synthetic_dataset("c3")  # [16*1024, 784] float32
+    data = synth.synthetic_dataset(CONFIG)  # [EPOCH_BATCHES * batch, d] float32
     params = synth.synthetic_generator_params(D_FEAT)
     gen = vgan_amd.Generator_big(synth.latent_size(D_FEAT), D_FEAT)
     with torch.no_grad():
@@ -146,7 +152,7 @@ def cpu_baseline(data, params, seconds):
         k += 1
     dt = time.perf_counter() - t0
     return {"value": k / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{k} VGAN_no_kl steps (batch=1024, d=784, fp32) of the PyTorch-CPU port in {dt:.1f} s"}, first_loss, (X, z)
+            "sample": f"{k} VGAN_no_kl steps (batch={N_BATCH}, d={D_FEAT}, fp32) of the PyTorch-CPU port in {dt:.1f} s"}, first_loss, (X, z)
 
 
 def gpu_first_loss(params, X, z, **engine_kw):
@@ -167,7 +173,13 @@ def gpu_first_loss(params, X, z, **engine_kw):
 
 
 def main():
+    global N_BATCH, D_FEAT, EPOCH_BATCHES, CONFIG, WORKLOAD
     args = parse()
+    CONFIG = args.workload
+    N_BATCH, D_FEAT, EPOCH_BATCHES, WORKLOAD = WORKLOADS[CONFIG]
+    if CONFIG != "c3":
+        args.steps, args.warmup = min(args.steps, 200), min(args.warmup, 8)
+        args.no_cpu_baseline = args.no_cpu_baseline or CONFIG == "c5"  # N = 16384: ~17 GB and ~15 s per CPU step
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -228,7 +240,7 @@ def main():
     if rank == 0:
         steps_per_s = args.steps / elapsed
         out = {
-            "metric": "V-GAN train steps/sec (batch=1024, d=784)", "value": steps_per_s, "unit": "steps/s",
+            "metric": f"V-GAN train steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": steps_per_s, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (MMD products: split-bf16 x3 on the bf16 MFMA, fp32 accumulate)" if eng.bf3 else "f32", "data": "synthetic",

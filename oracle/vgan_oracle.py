@@ -241,7 +241,8 @@ class NoKLTrainer:
 # --------------------------------------------------------------------------------------
 def synthetic_dataset(config: str, rows: int | None = None, seed: int = 0):
     """float32 datasets of SURVEY 8(d).  c1: 2-Gaussian mixture d=20; c2: musk stand-in d=166;
-    c3: MNIST-pixel stand-in d=784 (values in [0,1], ~80% zeros, rank-32 + noise)."""
+    c3: MNIST-pixel stand-in d=784 (values in [0,1], ~80% zeros, rank-32 + noise);
+    c4 / c5: synthetic tabular d=2048 / 4096, N(0,1) with 64 planted correlated feature blocks."""
     rng = np.random.default_rng(seed)
     if config == "c1":
         d, n = 20, 128
@@ -260,6 +261,16 @@ def synthetic_dataset(config: str, rows: int | None = None, seed: int = 0):
         low = rng.random(size=(rows, 32)) @ rng.random(size=(32, d)) / 16.0
         X = np.clip(low + 0.05 * rng.normal(size=(rows, d)), 0.0, 1.0)
         X = X * (rng.random(size=(rows, d)) < 0.2)
+    elif config in ("c4", "c5"):
+        # synthetic tabular: N(0,1) features with 64 planted correlated blocks (each block shares one latent factor)
+        d, n = (2048, 4096) if config == "c4" else (4096, 8192)
+        rows = rows or 4 * n
+        rng32 = np.random.default_rng(seed + (4 if config == "c4" else 5))
+        X = rng32.standard_normal(size=(rows, d), dtype=np.float32)
+        factors = rng32.standard_normal(size=(rows, 64), dtype=np.float32)
+        width = d // 128  # 64 blocks covering half of the features
+        for b in range(64):
+            X[:, 2 * b * width:(2 * b + 1) * width] = 0.6 * X[:, 2 * b * width:(2 * b + 1) * width] + 0.8 * factors[:, b:b + 1]
     else:
         raise ValueError(config)
     return np.ascontiguousarray(X, dtype=np.float32)

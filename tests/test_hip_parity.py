@@ -598,3 +598,117 @@ def test_finalize_job_riding_in_backward_equals_standalone_finalize(ops, bf3):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert int(a["counter"]) == 42 and float(a["loss"]) != 0.0
+
+
+# ---- BASELINE.json configs[3] / configs[4] at their full single-GPU sizes -------------------------------------------
+def _dy_rows_fp64(Z, n, bw, rows):
+    """Rows of dLoss/dY in float64 from the closed form: dY_i = (4/n^2) [sum_{j in Y} K'_ij (y_i - y_j)
+    - sum_{a in X} K'_ia (y_i - x_a)], K' = dK/dL of the 5-bandwidth RBF.  O(N d) per row, so usable at any size;
+    test_dy_rows_helper_matches_oracle pins it to oracle.mmd_backward."""
+    Z = np.asarray(Z)
+    out = []
+    sc = orc.rbf_scales(bw, np.dtype(np.float64))
+    for i in rows:
+        zi = Z[n + i].astype(np.float64)
+        diff = zi[None, :] - Z.astype(np.float64)            # [2n, d]
+        L = (diff * diff).sum(1)
+        dK = sum(-np.exp(-L / s) / s for s in sc)              # [2n]
+        sign = np.concatenate([-np.ones(n), np.ones(n)])
+        out.append((4.0 / (float(n) * n)) * ((sign * dK)[:, None] * diff).sum(0))
+    return np.stack(out)
+
+
+def test_dy_rows_helper_matches_oracle():
+    f = load_golden("f1_ops_n64_d12.npz")
+    X, U = f["X"].astype(np.float64), f["U_f64"]
+    Y = U * X
+    n = X.shape[0]
+    bw = float(orc.mmd_forward(X, Y, U, 0.0)["bw"])
+    dY, _ = orc.mmd_backward(X, Y, U, 0.0, bw)
+    rows = [0, 5, n - 1]
+    np.testing.assert_allclose(_dy_rows_fp64(np.vstack([X, Y]), n, bw, rows), dY[rows], rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_c4_full_size_step_vs_fp64_oracle(ops, precision):
+    """configs[3] (d=2048, batch=4096) on one GPU: loss / bandwidth of one whole step against the fp64 oracle (bar 1e-4),
+    sampled rows of the backward product against the closed form, and the 8-rank row sharding of the same batch
+    (tile tables of ranks 0..7) summing to the single-rank statistics."""
+    n, d = 4096, 2048
+    L = orc.latent_size(d)
+    data = orc.synthetic_dataset("c4", rows=n)
+    params = orc.synthetic_generator_params(d, seed=4)
+    z = np.random.default_rng(44).normal(size=(n, L)).astype(np.float32)
+    eng, _ = make_engine(ops, params, data, n, mmd_precision=precision)
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    eng.set_noise(torch.as_tensor(z))
+    eng.step()
+    p64 = [p.astype(np.float64) for p in params]
+    logits, _ = orc.generator_forward(p64, z.astype(np.float64))
+    U, _ = orc.upper_softmax_forward(logits)
+    X = data.astype(np.float64)
+    want = orc.mmd_forward(X, U * X, U, 10.0)
+    assert abs(float(eng.loss) - float(want["loss"])) < 1e-4, (float(eng.loss), float(want["loss"]))
+    np.testing.assert_allclose(float(eng.bw), float(want["bw"]), rtol=1e-5)
+    # backward product rows: gU = dY * X summed over the split-K slabs
+    rows = [0, 1234, n - 1]
+    Zh = host(eng.Z)[:, :d]
+    dY = _dy_rows_fp64(Zh, n, float(want["bw"]), rows)
+    gU = host(eng.gU_slabs.sum(0))[:, :d]
+    np.testing.assert_allclose(gU[rows], dY * data[rows], rtol=0, atol=2e-4 * np.abs(dY * data[rows]).max())
+    # data-parallel sharding of this batch over 8 ranks: per-rank block sums add up to the single-rank statistics
+    single = host(eng.stats).copy()
+    tot = np.zeros(4)
+    part = torch.empty(eng.tiles.shape[0], 4, device="cuda")
+    st = torch.empty(4, dtype=torch.float64, device="cuda")
+    for r in range(8):
+        tiles = ops.build_tiles(n, 1, r, 8)
+        assert tiles.shape[0] <= part.shape[0]
+        if precision == "bf16x3":
+            ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, tiles, None, None, 0, part)
+        else:
+            ops.mmd_gram(eng.Z, eng.sqn, n, eng.dp, eng.bw, tiles, False, None, 0, part)
+        ops.mmd_reduce(part, tiles, st, True)
+        tot += host(st)
+    np.testing.assert_allclose(tot[:3], single[:3], rtol=1e-9)
+
+
+def test_c5_full_size_properties(ops):
+    """configs[4] (d=4096, batch=8192, 5 kernels) on one GPU, where the oracle no longer finishes in seconds:
+    (1) a generator with zero weights gives U = 1, Y = X, so the whole step must return MMD^2 = 0 and a vanishing gradient;
+    (2) the fp32-MFMA and the split-bf16 kernels, two independent implementations, agree on loss, bandwidth and gradient;
+    (3) sampled rows of the backward product match the float64 closed form."""
+    n, d = 8192, 4096
+    L = orc.latent_size(d)
+    data = orc.synthetic_dataset("c5", rows=n)
+    z = np.random.default_rng(55).normal(size=(n, L)).astype(np.float32)
+    zero = [np.zeros_like(p) for p in orc.synthetic_generator_params(d)]
+    eng, _ = make_engine(ops, zero, data, n, mmd_precision="bf16x3")
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    eng.set_noise(torch.as_tensor(z))
+    eng.step()
+    assert abs(float(eng.loss)) < 1e-6, float(eng.loss)
+    assert float(eng.gU_slabs.sum(0).abs().max()) < 1e-9
+    del eng
+    torch.cuda.empty_cache()
+    params = orc.synthetic_generator_params(d, seed=5)
+    res = {}
+    for precision in ("fp32", "bf16x3"):
+        eng, _ = make_engine(ops, params, data, n, mmd_precision=precision)
+        eng.set_epoch_batches(torch.arange(n).view(1, n))
+        eng.set_noise(torch.as_tensor(z))
+        eng.step()
+        res[precision] = dict(loss=float(eng.loss), bw=float(eng.bw), stats=host(eng.stats).copy(),
+                              gU=host(eng.gU_slabs.sum(0))[:, :d], Z=host(eng.Z)[:, :d] if precision == "fp32" else None)
+        del eng
+        torch.cuda.empty_cache()
+    a, b = res["fp32"], res["bf16x3"]
+    assert abs(a["loss"] - b["loss"]) < 2e-6 and 0.0 < a["loss"] < 20.0
+    np.testing.assert_allclose(a["bw"], b["bw"], rtol=1e-6)
+    np.testing.assert_allclose(a["stats"][:3], b["stats"][:3], rtol=2e-6)
+    scale = np.abs(a["gU"]).max()
+    assert scale > 0 and np.abs(a["gU"] - b["gU"]).max() < 2e-4 * scale
+    rows = [3, 4097, n - 1]
+    dY = _dy_rows_fp64(a["Z"], n, a["bw"], rows)
+    for name in ("fp32", "bf16x3"):
+        np.testing.assert_allclose(res[name]["gU"][rows], dY * data[rows], rtol=0, atol=2e-4 * np.abs(dY * data[rows]).max())

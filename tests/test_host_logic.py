@@ -25,7 +25,7 @@ def test_epoch_batches_match_dataloader_rng_order():
 
 def test_synthetic_inputs_identical_to_oracle_copy():
     from vgan_amd import synth
-    for cfg, rows in [("c1", 300), ("c2", 200), ("c3", 64)]:
+    for cfg, rows in [("c1", 300), ("c2", 200), ("c3", 64), ("c4", 8), ("c5", 4)]:
         assert np.array_equal(synth.synthetic_dataset(cfg, rows=rows), orc.synthetic_dataset(cfg, rows=rows))
     for a, b in zip(synth.synthetic_generator_params(784), orc.synthetic_generator_params(784)):
         assert np.array_equal(a, b)
