@@ -217,6 +217,25 @@ int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const
                           const uint16_t* ZTl, int kn, int kp, const float* Z, int ldz, int wrow0, int nr,
                           int p, const float* mul, int ldmul, float* out, int ldo, int splits,
                           int64_t slab_stride, const vgan_finalize_job* finalize, vgan_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * Grouped small products: up to VGAN_GEMM_MAX_GROUP independent row-major GEMMs in one launch.
+ * Generator_big (src/models/Generator.py:61-66) has no activation between its Linear layers, so its
+ * forward/backward is a chain of small matrix products (see vgan_homogeneous_pack); products of one
+ * dependency level share a launch.  kind: NN C[m,n] = A[m,k] . B[k,n];  NT C = A[m,k] . B[n,k]^T;
+ * TN C = A[k,m]^T . B[k,n].  All operands row-major with leading dimensions lda / ldb / ldc.
+ * ------------------------------------------------------------------------------------------- */
+#define VGAN_GEMM_MAX_GROUP 4
+#define VGAN_GEMM_NN 0
+#define VGAN_GEMM_NT 1
+#define VGAN_GEMM_TN 2
+typedef struct vgan_gemm_problem {
+    const float* a;
+    const float* b;
+    float* c;
+    int32_t kind, m, n, k, lda, ldb, ldc, pad;
+} vgan_gemm_problem;
+int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_t stream);
+
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

@@ -298,6 +298,14 @@ class CpuOps:
             r = r * _np(mul)[:nr, :p]
         out[:nr, :p].copy_(torch.as_tensor(r))
 
+    def gemm_grouped(self, problems):
+        outs = []
+        for kind, A, B, C in problems:  # all reads before any write: the products are independent by contract
+            a, b = _np(A).astype(np.float64), _np(B).astype(np.float64)
+            outs.append(a @ b if kind == "NN" else a @ b.T if kind == "NT" else a.T @ b)
+        for (_, _, _, C), r in zip(problems, outs):
+            C.copy_(torch.as_tensor(r))
+
     # ---- optimiser / noise
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         if nslabs > 1:

@@ -37,19 +37,29 @@ def _worker(rank, world, port, steps, out_dir, mode):
             eng.set_epoch_batches(torch.as_tensor(g["idx"][t:t + 10].astype(np.int64)))
         eng.set_noise(torch.as_tensor(g["noise"][t]))
         eng.step()
-        losses.append(float(eng.loss))
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.array(losses), flat=eng.fp.flat.numpy(), bw=float(eng.bw))
+        losses.append(eng.step_loss())  # sums the per-rank shares (one tiny all-reduce; not part of the step)
+    # epoch means through the fit loop's accessor (accumulated on the device, reduced over the ranks when read)
+    eng.epoch_loss()
+    for t in range(steps, steps + 10):
+        if t % 10 == 0:
+            eng.set_epoch_batches(torch.as_tensor(g["idx"][t:t + 10].astype(np.int64)))
+        eng.set_noise(torch.as_tensor(g["noise"][t]))
+        eng.step()
+    epoch_mean = eng.epoch_loss() / 10.0  # make_engine accumulates with scale 1
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.array(losses), flat=eng.fp.flat.numpy(), bw=float(eng.bw),
+             epoch_mean=epoch_mean)
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,mode", [(2, "collapsed"), (4, "collapsed"), (2, "layered")])
 def test_row_sharded_dp_matches_single_process(world, mode, tmp_path):
-    steps = 25
+    steps = 20
     mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mode), nprocs=world, join=True)
     g = load_golden("f3_traj_c1.npz")
     outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for o in outs:
         assert np.abs(o["losses"] - g["losses"][:steps]).max() < 2e-5   # same statistic as the unsharded reference run
         np.testing.assert_allclose(o["bw"], float(g["bw"]), rtol=1e-5)
+        assert abs(float(o["epoch_mean"]) - g["losses"][steps:steps + 10].mean()) < 2e-5
         assert np.array_equal(o["flat"], outs[0]["flat"])              # replicas stay bit-identical

@@ -712,3 +712,35 @@ def test_c5_full_size_properties(ops):
     dY = _dy_rows_fp64(a["Z"], n, a["bw"], rows)
     for name in ("fp32", "bf16x3"):
         np.testing.assert_allclose(res[name]["gU"][rows], dY * data[rows], rtol=0, atol=2e-4 * np.abs(dY * data[rows]).max())
+
+
+@pytest.mark.parametrize("case", ["chain_c3", "ragged", "single_long_k"])
+def test_gemm_grouped_vs_numpy(ops, case):
+    """vgan_gemm_grouped: NN / NT / TN products of one launch against float64 numpy (shapes of the collapsed generator at
+    c3, shapes that are no multiple of 4 -- the scalar staging path -- and a single tall-skinny product)."""
+    rng = np.random.default_rng(31)
+    T = lambda *shape: torch.as_tensor(rng.normal(size=shape).astype(np.float32)).cuda()
+    if case == "chain_c3":
+        e = [52, 100, 200, 396, 788]
+        M4, Wt4, B3, B2, At3 = T(e[4], e[0]), T(e[4], e[3]), T(e[4], e[2]), T(e[4], e[1]), T(e[3], e[0])
+        probs = [("TN", Wt4, M4), ("TN", B3, M4), ("TN", B2, M4), ("NT", M4, At3)]
+    elif case == "ragged":
+        probs = [("NN", T(37, 45), T(45, 70)), ("NT", T(130, 19), T(67, 19)), ("TN", T(301, 33), T(301, 9))]
+    else:
+        probs = [("NN", T(96, 1000), T(1000, 40))]
+    full = []
+    for kind, A, B in probs:
+        a, b = host(A).astype(np.float64), host(B).astype(np.float64)
+        want = a @ b if kind == "NN" else a @ b.T if kind == "NT" else a.T @ b
+        C = torch.full(want.shape, float("nan"), device="cuda")
+        full.append((kind, A, B, C, want))
+    ops.gemm_grouped([(k, A, B, C) for k, A, B, C, _ in full])
+    for kind, A, B, C, want in full:
+        np.testing.assert_allclose(host(C), want, rtol=0, atol=2e-5 * np.abs(want).max(), err_msg=kind)
+    # strided views (leading dimension > width) as the engine passes them
+    big = T(64, 80)
+    A, B = big[:, :52], T(40, 52)
+    C = torch.zeros(64, 48, device="cuda")
+    ops.gemm_grouped([("NT", A, B, C[:, :40])])
+    np.testing.assert_allclose(host(C[:, :40]), host(A).astype(np.float64) @ host(B).astype(np.float64).T, rtol=0, atol=1e-4)
+    assert float(C[:, 40:].abs().max()) == 0.0

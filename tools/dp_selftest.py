@@ -24,9 +24,24 @@ for graph in (False, True):
         if t % bench.EPOCH_BATCHES == 0:
             eng.set_epoch_batches(torch.arange(bench.N_BATCH * bench.EPOCH_BATCHES).view(bench.EPOCH_BATCHES, -1))
         eng.step()
-        losses.append(float(eng.loss))
+        losses.append(eng.step_loss())
     torch.cuda.synchronize()
     if rank == 0:
         print(f"graph={graph} world={world}: losses {np.round(losses, 6).tolist()} captured={eng.graph is not None}")
+
+# Per-rank step time of a G-way row shard, measured on THIS GPU: the engine is built as rank 0 of G while the process
+# group has `world` members, so the kernels do exactly one rank's share and the collective is issued but is cheap.
+# A lower bound for the G-GPU step (the real all-reduce latency comes on top); numerics are meaningless here.
+import time
+if world == 1:
+    for G in (1, 2, 4, 8):
+        eng, data, params = bench.build_engine(0, G, True, force_exchange=True)
+        bench.run_steps(eng, 64, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bench.run_steps(eng, 800, 64)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 800
+        print(f"emulated shard 1/{G}: {dt * 1e6:.1f} us per step per rank ({1.0 / dt:.0f} steps/s if collectives were free)")
 dist.barrier()
 dist.destroy_process_group()

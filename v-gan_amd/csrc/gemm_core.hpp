@@ -487,14 +487,14 @@ struct GemmTileKS {
         const int fi = lane & 31, fh = lane >> 5;
         lds_f* const sA0 = lds;
         lds_f* const sB0 = lds + 2 * kImgA;
-        Stager<T, BK, LA, VEC> ga;
-        Stager<T, BK, LB, VEC> gb;
-        ga.init(A, lda, m0, M, K, tid);
-        gb.init(B, ldb, n0, N, K, tid);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const int nk = (K + BK - 1) / BK;
+        Stager<T, BK, LA, VEC> ga;
+        Stager<T, BK, LB, VEC> gb;
+        ga.init(A, lda, m0, M, K, tid);
+        gb.init(B, ldb, n0, N, K, tid);
         ga.load(0);
         gb.load(0);
         ga.store(sA0);

@@ -19,6 +19,15 @@ class FinalizeJob(ctypes.Structure):
                 ("d", ctypes.c_int32), ("weight", _f), ("accum_scale", _f)]
 
 
+class GemmProblem(ctypes.Structure):
+    """struct vgan_gemm_problem (include/vgan_hip.h)."""
+    _fields_ = [("a", _p), ("b", _p), ("c", _p), ("kind", ctypes.c_int32), ("m", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
+GEMM_MAX_GROUP = 4
+
 # name -> (restype, argtypes); must list every function declared in include/vgan_hip.h
 SIGNATURES = {
     "vgan_abi_version": (_i, []),
@@ -53,6 +62,7 @@ SIGNATURES = {
     "vgan_homogeneous_pack": (_i, [_p, _i, _i, _i, _p]),
     "vgan_chain_backward_stage": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _u64, _p, _p]),
+    "vgan_gemm_grouped": (_i, [_p, _i, _p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 

@@ -239,6 +239,26 @@ class HipOps:
                                                   ctypes.byref(finalize) if finalize is not None else None, self._stream()),
                    "vgan_mmd_backward_bf3")
 
+    def gemm_grouped(self, problems):
+        """problems: up to 4 tuples (kind, A, B, C) with kind in "NN" (C = A.B), "NT" (C = A.B^T), "TN" (C = A^T.B); 2-D float32
+        tensors with unit inner stride.  One launch; the products must not depend on each other."""
+        assert 1 <= len(problems) <= _lib.GEMM_MAX_GROUP
+        arr = (_lib.GemmProblem * len(problems))()
+        for q, (kind, A, B, C) in zip(arr, problems):
+            _mat(A, "A"), _mat(B, "B"), _mat(C, "C")
+            if kind == "NN":
+                (m, k), (k2, n), code = A.shape, B.shape, _lib.GEMM_NN
+            elif kind == "NT":
+                (m, k), (n, k2), code = A.shape, B.shape, _lib.GEMM_NT
+            elif kind == "TN":
+                (k, m), (k2, n), code = A.shape, B.shape, _lib.GEMM_TN
+            else:
+                raise ValueError(kind)
+            assert k == k2 and tuple(C.shape) == (m, n), (kind, tuple(A.shape), tuple(B.shape), tuple(C.shape))
+            q.a, q.b, q.c, q.kind, q.m, q.n, q.k = A.data_ptr(), B.data_ptr(), C.data_ptr(), code, m, n, k
+            q.lda, q.ldb, q.ldc = A.stride(0), B.stride(0), C.stride(0)
+        _lib.check(self.lib.vgan_gemm_grouped(arr, len(problems), self._stream()), "vgan_gemm_grouped")
+
     # ---- optimiser / noise / misc ----------------------------------------------------------------
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         """nslabs > 1: `g` is slab 0 of split-K gradient slabs `slab_stride` apart, summed inside the kernel."""

@@ -24,11 +24,17 @@ Generator (src/models/Generator.py:58-70 has NO activation between its Linear la
                of L+1 instead of the batch: ~0.2 GFLOP/step instead of 2.5 at d=784, same mathematics
                (different fp32 association; parity-tested like the layered path).
 
-Data parallel (exact): rank r owns rows [r*n/G, (r+1)*n/G) of the batch.  Exchange per
-step -- three small collectives: all-gather of the Y rows, all-gather of one {4 block statistics | d packed
-column arg-max keys} record per rank (folded in rank order by vgan_mmd_finalize_ranks), all-reduce(SUM)
-of the generator gradient (the flat gradient when layered; only M4, 10x smaller, when collapsed).  Every rank applies the identical
-Adadelta update.  The data set and the noise stream are replicated, so results do not depend on G.
+Data parallel (exact): the O(n^2 d) work -- the Gram row block, the backward product -- and the mask
+backward / weight-gradient contraction are sharded by rows: rank r owns rows [r*n/G, (r+1)*n/G) of the batch.  The
+O(n d) front of the step (generator forward, mask, projection: ~10 us) is REPLICATED instead of exchanged: the data
+set, the generator and the counter-based noise stream are replicated, so every rank can produce all n rows of U and Y
+bit-identically, and with them the column arg-max keys.  That leaves ONE collective per step: all-reduce(SUM) of the
+generator gradient (the flat gradient when layered; only M4, 10x smaller, when collapsed).  The loss is not needed by
+the gradient: each rank accumulates its share of the block sums (rank 0 adds the penalty) and the shares are summed
+once per epoch when the loss is read (`epoch_loss`, `step_loss`).  The bandwidth calibration of the first step is
+replicated too.  Every rank applies the identical Adadelta update; results do not depend on G.
+(An earlier version exchanged Y rows and a statistics record: three collectives per step, each ~a fifth of the
+single-GPU step time at c3.)
 
 Measured and rejected (MI355X, ROCm 7.2, c3): a fork/join HIP graph (XX tiles and weight-gradient GEMMs
 on side streams) replays SLOWER than the plain chain (357 vs 313 us/step): each cross-stream edge costs
@@ -120,13 +126,14 @@ class NoKLStepEngine:
         self.za = torch.zeros(n, self.e[0], **f32)       # [z | 1 | 0-pad] for ALL batch rows (noise stream is replicated)
         self.za[:, L] = 1.0
         self.z_own = self.za[self.lo:self.lo + nl]
-        self.logits = torch.zeros(nl, d, **f32)
+        self.logits = torch.zeros(n, d, **f32)           # all rows on every rank (replicated front, see the module docstring)
         if self.mode == "layered":
             self.gslab = torch.zeros(self.splits, self.fp.total, **f32) if self.splits > 1 else None
             gbase = self.gslab[0] if self.splits > 1 else self.fp.grad
             self.dW = [self.fp.view(gbase, 2 * k) for k in range(4)]
             self.db = [self.fp.view(gbase, 2 * k + 1) for k in range(4)]
-            self.acts = [self.z_own[:, :L]] + [torch.zeros(nl, w, **f32) for w in self.widths[1:4]] + [self.logits]
+            self.acts = [self.za[:, :L]] + [torch.zeros(n, w, **f32) for w in self.widths[1:4]] + [self.logits]
+            self.acts_own = [a[self.lo:self.lo + nl] for a in self.acts]
             self.dacts = [None] + [torch.zeros(nl, w, **f32) for w in self.widths[1:4]]
         else:
             e = self.e
@@ -141,6 +148,10 @@ class NoKLStepEngine:
             self.Gt = [None] + [self.Gt_all[poff[k - 1]:poff[k]].view(e[k], e[k - 1]) for k in range(1, 5)]
             self.At = [None, self.Wt[1]] + [torch.zeros(e[k], e[0], **f32) for k in range(2, 5)]  # Wt_k .. Wt_1 (At_1 = Wt_1)
             self.M = [None, self.Gt[1]] + [torch.zeros(e[k], e[0], **f32) for k in range(2, 5)]   # M_1 IS Gt_1 (At_0 = I)
+            # suffix products B_3 = Wt_4 Wt_3 and B_2 = B_3 Wt_2: with them every M_k is one product away from M_4 and At_4 one
+            # product away from At_2, so the chain is 3 + 2 dependent launches instead of 4 + 3 (each ~5 us whatever its size)
+            self.B3 = torch.zeros(e[4], e[2], **f32)
+            self.B2 = torch.zeros(e[4], e[1], **f32)
             pmap = torch.full((self.fp.total,), -1, dtype=torch.int32)
             for k in range(1, 5):
                 wk, wk1 = self.widths[k], self.widths[k - 1]
@@ -169,7 +180,8 @@ class NoKLStepEngine:
             self.precision = "bf16x3" if 2 * n * d >= (1 << 20) else "fp32"
         self.bf3 = self.precision == "bf16x3"
         self._fin = None  # finalize job (raw pointers of the tensors below), built at first use
-        self.S = torch.zeros(nl, d, **f32)
+        self.S = torch.zeros(n, d, **f32)
+        self.S_own = self.S[self.lo:self.lo + nl]
         self.Z = torch.zeros(2 * n, dp, **f32)
         self.sqn = torch.zeros(2 * n, **f32)
         self.Wg = torch.zeros(nl, 2 * n, **f32)
@@ -191,7 +203,9 @@ class NoKLStepEngine:
             self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev)
-        self.partial = torch.zeros(self.tiles.shape[0], 4, **f32)
+        # the first-call bandwidth needs sum(L) over ALL pairs: computed by every rank from the full table (no collective)
+        self.tiles_cal = self.tiles if world == 1 else ops.build_tiles(n, 0, 0, 1, device=self.dev)
+        self.partial = torch.zeros(max(self.tiles.shape[0], self.tiles_cal.shape[0]), 4, **f32)
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
         self.has_bw = False
@@ -199,14 +213,8 @@ class NoKLStepEngine:
         self.loss_accum = torch.zeros(1, **f32)
         self.accum_scale = (1.0 / self.nb) if loss_accum_scale is None else float(loss_accum_scale)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.colpart = torch.zeros(ops.colmax_chunks(nl) * d, dtype=torch.int64, device=self.dev)
+        self.colpart = torch.zeros(ops.colmax_chunks(n) * d, dtype=torch.int64, device=self.dev)
         self.colkey = torch.zeros(d, dtype=torch.int64, device=self.dev)
-        if self.exchange:
-            # one exchange record per rank: {block statistics (4 f64) | column arg-max keys (d u64)} -> ONE all-gather
-            self.xrec = torch.zeros(4 + d, dtype=torch.int64, device=self.dev)
-            self.xstats = self.xrec[:4].view(torch.float64)
-            self.xkeys = self.xrec[4:]
-            self.xall = torch.zeros(world, 4 + d, dtype=torch.int64, device=self.dev)
 
     # ---- host-side controls ---------------------------------------------------------------------
     def set_epoch_batches(self, idx):
@@ -224,9 +232,20 @@ class NoKLStepEngine:
     def epoch_loss(self):
         """Mean loss of the steps since the last call (one host sync), as the reference's
         ``generator_loss += loss / batch_number`` (src/vgan.py:620-621)."""
-        v = float(self.loss_accum.item())
+        v = float(self._sum_over_ranks(self.loss_accum).item())
         self.loss_accum.zero_()
         return v
+
+    def step_loss(self):
+        """Loss of the last step (one host sync; with several ranks also one tiny all-reduce: `loss` holds this rank's share)."""
+        return float(self._sum_over_ranks(self.loss).item())
+
+    def _sum_over_ranks(self, t):
+        if not self.exchange:
+            return t
+        t = t.clone()
+        self._collect().all_reduce(t, group=self.group)
+        return t
 
     def grad_view(self, k):
         """Gradient of parameter tensor k as of the last step (sums split-K slabs that Adadelta consumed directly)."""
@@ -243,9 +262,11 @@ class NoKLStepEngine:
             for k in range(4):
                 ops.linear_forward(self.acts[k], self.W[k], self.b[k], self.acts[k + 1])
             return
-        for k in (2, 3, 4):  # At_k = Wt_k . At_{k-1}   (Wt is kept current by the optimiser)
-            ops.linear_backward_input(self.Wt[k], self.At[k - 1], self.At[k])
-        ops.linear_forward(self.z_own, self.At[4][:self.d], None, self.logits)
+        # prefix products At_k = Wt_k .. Wt_1 (Wt is kept current by the optimiser), two dependency levels:
+        Wt, At = self.Wt, self.At
+        ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3)])
+        ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
+        ops.linear_forward(self.za, At[4][:self.d], None, self.logits)
 
     def _m_operand(self, k, reduced):
         """M_k as a GEMM operand: (tensor, nslabs, slab_stride).  The slabs are reduced by their own launch: letting the
@@ -265,7 +286,7 @@ class NoKLStepEngine:
         if self.mode == "layered":
             g = self.dlogits
             for k in (3, 2, 1, 0):
-                ops.linear_backward_params(g, self.acts[k], self.dW[k], self.db[k], self.splits, self.fp.total)
+                ops.linear_backward_params(g, self.acts_own[k], self.dW[k], self.db[k], self.splits, self.fp.total)
                 if k:
                     ops.linear_backward_input(g, self.W[k], self.dacts[k])
                     g = self.dacts[k]
@@ -288,9 +309,12 @@ class NoKLStepEngine:
             self._m_operand(4, reduced=True)
         if dist:
             dist.all_reduce(self.M[4], group=self.group)
-        # stage k: M_{k-1} = Wt_k^T . M_k  and  [dW_k | db_k] = M_k . At_{k-1}^T  in one launch (k = 1: At_0 = I, Gt_1 is M_1)
-        for k in (4, 3, 2):
-            ops.chain_backward_stage(self.Wt[k], self.M[k], self.At[k - 1], self.M[k - 1], self.Gt[k])
+        # M_{k-1} = Wt_k^T M_k, i.e. M_3 = Wt_4^T M_4, M_2 = B_3^T M_4, M_1 = B_2^T M_4 (At_0 = I: Gt_1 IS M_1), and
+        # [dW_k | db_k] = Gt_k = M_k . At_{k-1}^T: two dependency levels
+        M, Gt, At = self.M, self.Gt, self.At
+        ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1]),
+                          ("NT", M[4], At[3], Gt[4])])
+        ops.gemm_grouped([("NT", M[3], At[2], Gt[3]), ("NT", M[2], At[1], Gt[2])])
         fused_noise = dict(next_noise=self.za, noise_cols=self.L, noise_ones_col=self.L, seed=self.seed,
                            step_counter=self.step_counter) if self.noise_mode == "device" else {}
         ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
@@ -307,25 +331,14 @@ class NoKLStepEngine:
             ops.noise_normal(self.za, self.seed, self.step_counter, 0, cols=self.L, ones_col=self.L)
         self._generator_forward()
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
-        if not self.exchange:
-            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n],
-                                     self.sqn[n:], row_offset=0, **rowsel)
-        else:
-            dist = self._collect()
-            ops.gather_rows(self.data, self.perm, self.Z[:n], self.sqn[:n], row_offset=0, **rowsel)
-            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, None, self.Z[n + lo:n + lo + nl], None,
-                                     self.sqn[n + lo:n + lo + nl], row_offset=lo, **rowsel)
-            dist.all_gather_into_tensor(self.Z[n:], self.Z[n + lo:n + lo + nl], group=self.group)
-            ops.row_sqnorm(self.Z[n:], self.sqn[n:], self.dp)  # norms of all Y rows: a 5 us kernel instead of a second collective
+        ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n], self.sqn[n:],
+                                 row_offset=0, **rowsel)
 
     def _calibrate(self):
         """First-call bandwidth (src/models/Mmd_loss_constrained.py:16-20): sum(L) / (N^2 - N)."""
         ops = self.ops
-        ops.mmd_gram(self.Z, self.sqn, self.n, self.dp, None, self.tiles, True, None, 0, self.partial)
-        ops.mmd_reduce(self.partial, self.tiles, self.stats, True)
-        if self.exchange:
-            dist = self._collect()
-            dist.all_reduce(self.stats, group=self.group)
+        ops.mmd_gram(self.Z, self.sqn, self.n, self.dp, None, self.tiles_cal, True, None, 0, self.partial)
+        ops.mmd_reduce(self.partial, self.tiles_cal, self.stats, True)
         ops.mmd_set_bandwidth(self.stats, self.n, self.bw)
         self.has_bw = True
 
@@ -333,40 +346,30 @@ class NoKLStepEngine:
         ops, n, nl, lo, d = self.ops, self.n, self.nl, self.lo, self.d
         dist = self._collect() if self.exchange else None
         gstride = nl * self.dp
-        fin = None
         bf3 = self.precision == "bf16x3"
         if bf3:
             ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
-        if dist is None:
-            if bf3:
-                ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial, self.S, lo,
-                                 self.colpart, True)
-            else:
-                ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, lo,
-                                    self.colpart, True)
-            # the step tail (block sums -> stats, column keys, loss bookkeeping) rides in the backward launch as one extra
-            # workgroup: its outputs are first needed by the mask backward, so it leaves the critical path
-            if self._fin is None:
-                self._fin = ops.finalize_job(self.partial, self.tiles, self.colpart, ops.colmax_chunks(nl), self.colkey, n, d, self.pen,
-                                             self.stats, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
-            fin = self._fin
+        if bf3:
+            ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
+                             self.colpart, True)
         else:
-            ops.colmax(self.S, lo, self.colpart, self.xkeys, True)
-            if bf3:
-                ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial)
-            else:
-                ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, False, self.Wg, n + lo, self.partial)
-            ops.mmd_reduce(self.partial, self.tiles, self.xstats, True)
-            dist.all_gather_into_tensor(self.xall.view(-1), self.xrec, group=self.group)
-            ops.mmd_finalize_ranks(self.xall, self.world, d, n, self.pen, self.stats, self.colkey, self.loss, self.loss_accum,
-                                   self.accum_scale, self.step_counter)
+            ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, 0,
+                                self.colpart, True)
+        # the step tail (block sums -> stats, column keys, loss bookkeeping) rides in the backward launch as one extra
+        # workgroup: its outputs are first needed by the mask backward, so it leaves the critical path.  With several
+        # ranks `stats` / `loss` are this rank's share (its tiles); the penalty is added by rank 0 only.
+        if self._fin is None:
+            self._fin = ops.finalize_job(self.partial, self.tiles, self.colpart, ops.colmax_chunks(n), self.colkey, n, d,
+                                         self.pen if self.rank == 0 else 0.0, self.stats, self.loss, self.loss_accum, self.accum_scale,
+                                         self.step_counter)
+        fin = self._fin
         if bf3:
             ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
                                  gstride, fin)
-            ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
+            ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         else:
             ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride, fin)
-            ops.mask_backward(self.gU, self.S, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
+            ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         self._generator_backward_update(dist)
 
     def _step_body(self):
