@@ -110,8 +110,9 @@ def kernel_rooflines(eng):
     add("mmd_backward_kernel<4,2>", time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU)))
     if eng.bf3:
         gs = nl * eng.dp
-        add("mmd_gram_bf3_kernel<64>", time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles, eng.Wh, eng.Wl,
-                                                                         n + lo, eng.partial)))
+        gname = "mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"
+        add(gname, time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles, eng.Wh, eng.Wl, n + lo, eng.partial,
+                                                        tile=eng.gram_tile)))
         add("mmd_backward_bf3_kernel<64>", time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d,
                                                                                  eng.Z[lo:lo + nl], eng.gU, eng.bsplits, gs)))
         out["bf3_prepare_kernel"] = {"ms": time_kernel(lambda: ops.mmd_bf3_prepare(eng.Z, 2 * n, d, eng.Zh, eng.Zl, eng.ZTh, eng.ZTl))}
@@ -247,7 +248,7 @@ def main():
             "config": {"workload": WORKLOAD, "global_batch": N_BATCH, "features": D_FEAT, "latent": eng.L,
                        "rows_per_gpu": eng.nl, "parallelism": f"dp{world} (row-sharded Gram, replicated generator)",
                        "hip_graph": bool(use_graph), "mean_loss": mean_loss, "prewarm_s": args.prewarm_seconds,
-                       "generator": eng.mode, "mmd_precision": eng.precision},
+                       "generator": eng.mode, "mmd_precision": eng.precision, "gram_tile": eng.gram_tile},
         }
         def traffic_of(kernel):
             tp = os.path.join(ROOT, "profiles", "traffic.json")
@@ -263,7 +264,7 @@ def main():
             # The dominant kernel issues v_mfma_f32_32x32x16_bf16; `achieved` is ALGORITHMIC flops / launch time as the
             # contract says, `peak` the dense bf16 MFMA rate.  Each algorithmic product costs three bf16 products
             # (hi.hi' + hi.lo' + lo.hi'), so the executed MFMA rate is 3x `achieved`; both fractions are reported.
-            name, peak = "mmd_gram_bf3_kernel<64>", BF16_MFMA_PEAK_TFLOPS
+            name, peak = ("mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"), BF16_MFMA_PEAK_TFLOPS
             g = kern[name]
             extra = {"executed_mfma_tflops": 3.0 * g["tflops"], "executed_frac": 3.0 * g["tflops"] / peak,
                      "vs_fp32_mfma_peak": g["tflops"] / FP32_MFMA_PEAK_TFLOPS,

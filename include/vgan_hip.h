@@ -27,7 +27,7 @@ extern "C" {
 #define VGAN_ERR_ARG 1  /* bad shape / null pointer / unsupported configuration */
 #define VGAN_ERR_HIP 2  /* a HIP runtime call or launch failed */
 
-#define VGAN_ABI_VERSION 1
+#define VGAN_ABI_VERSION 2
 
 typedef void* vgan_stream_t; /* hipStream_t */
 
@@ -116,7 +116,7 @@ int vgan_upper_softmax_forward(const float* logits, int ldl, float* S, float* U,
  * Work is described by a tile table (host-built by vgan_mmd_build_tiles, uploaded by the caller):
  * each entry is 8 int32 {r0, c0, rlim, clim, flags, 0,0,0}.
  * ------------------------------------------------------------------------------------------- */
-#define VGAN_TILE 64           /* Gram tile edge */
+#define VGAN_TILE 64           /* Gram tile edge of the fp32 kernels; the split-bf16 Gram also has a 128 variant */
 #define VGAN_TILE_INTS 8
 #define VGAN_TF_SLOT_MASK 3    /* 0 = XX, 1 = XY, 2 = YY  block sum the tile contributes to */
 #define VGAN_TF_TWICE 4        /* off-diagonal tile of a symmetric block: counted twice */
@@ -128,8 +128,9 @@ int vgan_upper_softmax_forward(const float* logits, int ldl, float* S, float* U,
  * wrow0 = n), 2 = gradient for all rows (Wg is [2n, 2n], wrow0 = 0).
  * Row-sharded data parallel: rank `rank` of `world` owns rows [rank*n/world, (rank+1)*n/world)
  * of each half; its table covers exactly the pairs (own row, any column), without symmetry.
+ * tile: edge of the square tiles, 64 (every kernel) or 128 (vgan_mmd_gram_bf3 only).
  * Returns the number of tiles (or -1 if cap is too small); out may be NULL to query the count. */
-int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int32_t* out, int cap);
+int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int tile, int32_t* out, int cap);
 
 /* partial[tiles*4] (float): per tile {sum K, sum L, 0, 0}.  calibrate != 0: only sum L is
  * produced (first-call bandwidth, Mmd_loss_constrained.py:16-20) and bw/Wg are not touched. */
@@ -205,10 +206,12 @@ int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wro
 int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, uint16_t* Zh, uint16_t* Zl, int kp,
                          uint16_t* ZTh, uint16_t* ZTl, int kn, vgan_stream_t stream);
 /* vgan_mmd_gram_colmax on the split operands; the gradient weights leave as a bf16 hi/lo pair Wh, Wl
- * [nr, ldw] (ldw >= 2n rounded up to 64; columns >= 2n must be pre-zeroed).  S may be NULL (no column job). */
+ * [nr, ldw] (ldw >= 2n rounded up to 64; columns >= 2n must be pre-zeroed).  S may be NULL (no column job).
+ * tile = the edge the table was built with: 64, or 128 (512-thread workgroups, half the L2->LDS bytes per
+ * flop; pays when the table still has >~ 128 tiles). */
 int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
-                      const int32_t* tiles, int ntiles, uint16_t* Wh, uint16_t* Wl, int ldw, int wrow0,
-                      float* partial, const float* S, int lds, int from_softmax, int row_offset,
+                      const int32_t* tiles, int ntiles, int tile, uint16_t* Wh, uint16_t* Wl, int ldw,
+                      int wrow0, float* partial, const float* S, int lds, int from_softmax, int row_offset,
                       uint64_t* colpart, int nrows, int d, vgan_stream_t stream);
 /* vgan_mmd_backward on the split operands: out = 2 (rowsum(W) z - W . Z) * mul with W = Wh + Wl [nr, kn]
  * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue.  splits / slab_stride as in

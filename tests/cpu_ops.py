@@ -25,8 +25,8 @@ class CpuOps:
     def __init__(self):
         self.lib = _lib.load()  # host-side helpers of the .so (tile tables) work without a GPU
 
-    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None):
-        flat, cnt = _lib.build_tiles(n, grad_mode, rank, world)
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64):
+        flat, cnt = _lib.build_tiles(n, grad_mode, rank, world, tile)
         return torch.tensor(flat, dtype=torch.int32).view(cnt, 8)
 
     def colmax_chunks(self, n):
@@ -257,13 +257,14 @@ class CpuOps:
     def _bf(t):
         return t.view(torch.bfloat16).double().numpy()
 
-    def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True):
+    def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True,
+                     tile=64):
         zh, zl = self._bf(Zh), self._bf(Zl)
         s = _np(sq).astype(np.float64)
         bwv = float(bw.reshape(-1)[0])
         part = np.zeros((tiles.shape[0], 4), dtype=np.float32)
         for t, (r0, c0, rlim, clim, fl, *_rest) in enumerate(tiles.tolist()):
-            ri, cj = np.arange(r0, min(r0 + 64, rlim)), np.arange(c0, min(c0 + 64, clim))
+            ri, cj = np.arange(r0, min(r0 + tile, rlim)), np.arange(c0, min(c0 + tile, clim))
             g = zh[ri] @ zh[cj].T + zh[ri] @ zl[cj].T + zl[ri] @ zh[cj].T
             L = np.maximum(s[ri][:, None] + s[cj][None, :] - 2 * g, 0.0)
             K = np.zeros_like(L)

@@ -6,15 +6,15 @@ import pytest
 
 from vgan_amd import lib
 
-T, SLOT, TWICE, STORE, MIRROR, NEG = 64, 3, 4, 8, 16, 32
+SLOT, TWICE, STORE, MIRROR, NEG = 3, 4, 8, 16, 32
 
 
-def table(n, mode, rank=0, world=1):
-    flat, cnt = lib.build_tiles(n, mode, rank, world)
+def table(n, mode, rank=0, world=1, tile=64):
+    flat, cnt = lib.build_tiles(n, mode, rank, world, tile)
     return np.array(flat, dtype=np.int64).reshape(cnt, 8)
 
 
-def coverage(n, tabs, nrW, wrow0s):
+def coverage(n, tabs, nrW, wrow0s, T=64):
     """Returns (count matrix [2n,2n] of how often the sums see each pair, writes matrix)."""
     N = 2 * n
     seen = np.zeros((N, N))
@@ -39,12 +39,13 @@ def coverage(n, tabs, nrW, wrow0s):
     return seen, writes, slot_ok
 
 
+@pytest.mark.parametrize("tile", [64, 128])
 @pytest.mark.parametrize("n", [1, 63, 64, 100, 128, 500, 1024])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_single_rank_tables(n, mode):
-    tab = table(n, mode)
+def test_single_rank_tables(n, mode, tile):
+    tab = table(n, mode, tile=tile)
     assert len({tuple(r[:2]) for r in tab.tolist()}) == len(tab), "duplicate tile after XCD interleave"
-    seen, writes, slot_ok = coverage(n, [tab], None, [n if mode == 1 else 0])
+    seen, writes, slot_ok = coverage(n, [tab], None, [n if mode == 1 else 0], tile)
     assert slot_ok
     N = 2 * n
     want = np.ones((N, N))
@@ -58,10 +59,11 @@ def test_single_rank_tables(n, mode):
         assert np.array_equal(writes, np.ones((N, N)))
 
 
+@pytest.mark.parametrize("tile", [64, 128])
 @pytest.mark.parametrize("n,world", [(128, 2), (512, 8), (1024, 4), (96, 3)])
-def test_row_sharded_tables(n, world):
-    tabs = [table(n, 1, r, world) for r in range(world)]
-    seen, writes, slot_ok = coverage(n, tabs, None, [0] * world)
+def test_row_sharded_tables(n, world, tile):
+    tabs = [table(n, 1, r, world, tile) for r in range(world)]
+    seen, writes, slot_ok = coverage(n, tabs, None, [0] * world, tile)
     assert slot_ok
     N = 2 * n
     want = np.ones((N, N))
@@ -76,7 +78,8 @@ def test_row_sharded_tables(n, world):
 
 def test_bad_arguments():
     l = lib.load()
-    assert l.vgan_mmd_build_tiles(0, 1, 0, 1, None, 0) == -1
-    assert l.vgan_mmd_build_tiles(64, 3, 0, 1, None, 0) == -1
-    assert l.vgan_mmd_build_tiles(64, 2, 0, 2, None, 0) == -1
+    assert l.vgan_mmd_build_tiles(0, 1, 0, 1, 64, None, 0) == -1
+    assert l.vgan_mmd_build_tiles(64, 3, 0, 1, 64, None, 0) == -1
+    assert l.vgan_mmd_build_tiles(64, 2, 0, 2, 64, None, 0) == -1
     assert b"grad_mode 2" in l.vgan_last_error()
+    assert l.vgan_mmd_build_tiles(64, 1, 0, 1, 96, None, 0) == -1  # only 64 and 128 exist

@@ -254,4 +254,116 @@ struct GemmBF3 {
     }
 };
 
+
+// ---- 128x128 output tile, 512 threads: 8 waves as 2 (rows) x 4 (columns), each wave two stacked 32x32 sub-tiles ----
+// The 64x64 kernel moves (64 + 64) rows x 64 k x 2 images x 2 B = 32 KB from L2 into LDS per K tile and tile; at the
+// metric's size that is 220 MB per launch, and the measured main loop time (10 us) is exactly that traffic at ~22 TB/s --
+// the aggregate L2 -> CU rate.  Doubling the tile edge halves the bytes per flop (113 MB) and the LDS fill per flop; the
+// 136 tiles of that size still fill more than half of the CUs, and the loop becomes MFMA-bound (128 x 128 x K x 6 flop per
+// CU at 4 x 1017 flop/cycle: 8.4 us).  Chosen by the caller (tile argument of vgan_mmd_build_tiles / vgan_mmd_gram_bf3).
+struct GemmBF3Big {
+    static constexpr int BM = 128, BN = 128, BK = 64, NTH = 512;
+    static constexpr int ROWB = (BK + 8) * 2;      // 144 B per LDS row (36 dwords = 4 * odd)
+    static constexpr int PART = BM * ROWB;         // one operand part (128 rows)
+    static constexpr int BUF = 4 * PART;           // Ah | Al | Bh | Bl
+    static constexpr int kLdsBytes = 2 * BUF;      // double buffered: 147,456 B -> one workgroup per CU
+
+    struct Stage {
+        u32x4 v[4][2];
+        const char* src[4][2];
+        int lofs[2];
+        __device__ __forceinline__ void init(const unsigned short* Ah, const unsigned short* Al, long lda, int m0, int M,
+                                             const unsigned short* Bh, const unsigned short* Bl, long ldb, int n0, int N, int tid) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int f = tid + NTH * r, row = f >> 3, q = f & 7;
+                const long ra = (long)min(m0 + row, M - 1) * lda + 8 * q, rb = (long)min(n0 + row, N - 1) * ldb + 8 * q;
+                src[0][r] = reinterpret_cast<const char*>(Ah + ra);
+                src[1][r] = reinterpret_cast<const char*>(Al + ra);
+                src[2][r] = reinterpret_cast<const char*>(Bh + rb);
+                src[3][r] = reinterpret_cast<const char*>(Bl + rb);
+                lofs[r] = row * ROWB + q * 16;
+            }
+        }
+        __device__ __forceinline__ void load(int k0) {
+#pragma unroll
+            for (int part = 0; part < 4; ++part)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) v[part][r] = *reinterpret_cast<const u32x4*>(src[part][r] + 2 * (long)k0);
+        }
+        __device__ __forceinline__ void store(char __attribute__((address_space(3)))* buf) const {
+#pragma unroll
+            for (int part = 0; part < 4; ++part)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) *(lds_u4*)(buf + part * PART + lofs[r]) = v[part][r];
+        }
+    };
+
+    // acc[i] (+)= A[m0 + 64 wr + 32 i .., :] . B[n0 + 32 wc .., :]^T over K (a multiple of 64)
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K,
+                                               char* lds_generic, f32x16 (&acc)[2]) {
+        typedef char __attribute__((address_space(3))) lds_c;
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wr = wave >> 2, wc = wave & 3;
+        const int fi = lane & 31, fh = lane >> 5;
+        Stage st;
+        st.init(Ah, Al, lda, m0, M, Bh, Bl, ldb, n0, N, tid);
+        const int nk = K / BK;
+        st.load(0);
+        st.store(lds);
+        if (nk > 1) st.load(BK);
+        __syncthreads();
+        auto body = [&](int kt, auto store_next, auto load_next2) {
+            const lds_c* buf = lds + (kt & 1) * BUF;
+            const lds_c* pa = buf + (wr * 64 + fi) * ROWB + fh * 16;
+            const lds_c* pb = buf + 2 * PART + (wc * 32 + fi) * ROWB + fh * 16;
+            u32x4 ah[2][4], al[2][4], bh[4], bl[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i][s] = *(const lds_u4*)(pa + i * 32 * ROWB + s * 32);
+                    al[i][s] = *(const lds_u4*)(pa + PART + i * 32 * ROWB + s * 32);
+                }
+                bh[s] = *(const lds_u4*)(pb + s * 32);
+                bl[s] = *(const lds_u4*)(pb + PART + s * 32);
+            }
+            if constexpr (decltype(store_next)::value) st.store(lds + ((kt & 1) ^ 1) * BUF);
+            if constexpr (decltype(load_next2)::value) st.load((kt + 2) * BK);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[s]), yl = __builtin_bit_cast(bf16x8, bl[s]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i][s]), xl = __builtin_bit_cast(bf16x8, al[i][s]);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i], 0, 0, 0);  // small terms first
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_iglp_opt(0);
+            __syncthreads();
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) body(kt, T{}, T{});
+        if (kt + 1 < nk) {
+            body(kt, T{}, F{});
+            ++kt;
+        }
+        body(kt, F{}, F{});
+    }
+    __device__ static __forceinline__ int sub_row(int i, int r) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave >> 2) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int sub_col() {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        return (wave & 3) * 32 + (lane & 31);
+    }
+};
+
 }  // namespace vgan

@@ -299,12 +299,12 @@ static uint64_t morton_key(uint32_t r, uint32_t c) {
     for (int b = 0; b < 16; ++b) k |= ((uint64_t)((r >> b) & 1) << (2 * b + 1)) | ((uint64_t)((c >> b) & 1) << (2 * b));
     return k;
 }
-static void order_tiles_for_xcds(int32_t* tiles, int count) {
+static void order_tiles_for_xcds(int32_t* tiles, int count, int T) {
     constexpr int NX = 8;
     std::vector<std::array<int32_t, VGAN_TILE_INTS>> v(count);
     for (int t = 0; t < count; ++t) std::memcpy(v[t].data(), tiles + (size_t)t * VGAN_TILE_INTS, sizeof(int32_t) * VGAN_TILE_INTS);
-    std::stable_sort(v.begin(), v.end(), [](const auto& a, const auto& b) {
-        return morton_key(a[0] / VGAN_TILE, a[1] / VGAN_TILE) < morton_key(b[0] / VGAN_TILE, b[1] / VGAN_TILE);
+    std::stable_sort(v.begin(), v.end(), [T](const auto& a, const auto& b) {
+        return morton_key(a[0] / T, a[1] / T) < morton_key(b[0] / T, b[1] / T);
     });
     const int q = count / NX, r = count % NX;
     int src = 0;
@@ -320,12 +320,12 @@ extern "C" const char* vgan_last_error(void) { return g_err; }
 // Host-side tile table.  Single rank: symmetric blocks use the upper triangle only (TWICE + MIRROR);
 // the XY block is laid out with rows in the Y half and columns in the X half so that Wg ([n,2n],
 // wrow0 = n) needs no transposed store for it.  Row-sharded ranks cover (own rows) x (all columns).
-extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int32_t* out, int cap) {
-    if (n <= 0 || grad_mode < 0 || grad_mode > 2 || world < 1 || rank < 0 || rank >= world) {
+extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int tile, int32_t* out, int cap) {
+    if (n <= 0 || grad_mode < 0 || grad_mode > 2 || world < 1 || rank < 0 || rank >= world || (tile != 64 && tile != 128)) {
         set_error("vgan_mmd_build_tiles: bad argument");
         return -1;
     }
-    const int T = VGAN_TILE;
+    const int T = tile;
     int count = 0;
     auto emit = [&](int r0, int c0, int rlim, int clim, int flags) {
         if (out != nullptr && count < cap) {
@@ -373,7 +373,7 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
             for (int c = 0; c < n; c += T) emit(n + r, n + c, n + hi, 2 * n, 2 | (grad_mode ? VGAN_TF_STORE : 0));
     }
     if (out != nullptr && count > cap) return -1;
-    if (out != nullptr) order_tiles_for_xcds(out, count);
+    if (out != nullptr) order_tiles_for_xcds(out, count, T);
     return count;
 }
 

@@ -183,6 +183,115 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_gram_bf3_kernel(
     if (threadIdx.x == 0) reinterpret_cast<float4*>(partial)[blockIdx.x] = make_float4((red[0] + red[1]) + (red[2] + red[3]), 0.f, 0.f, 0.f);
 }
 
+// ---- the same Gram tile + epilogue on 128x128 tiles (GemmBF3Big: 512 threads, one workgroup per CU) ------------------
+__global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned short* __restrict__ Zh, const unsigned short* __restrict__ Zl,
+                                                                  int kp, const float* __restrict__ sq, int n,
+                                                                  const float* __restrict__ bw_ptr, const TileDesc* __restrict__ tiles,
+                                                                  int ntiles, unsigned short* __restrict__ Wh,
+                                                                  unsigned short* __restrict__ Wl, int ldw, int wrow0,
+                                                                  float* __restrict__ partial, ColmaxJob cj) {
+    using G = GemmBF3Big;
+    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
+    __shared__ float red[8];
+    if ((int)blockIdx.x >= ntiles) {
+        const int cb = blockIdx.x - ntiles;
+        colmax_partial_body<8>(cj.S, cj.lds, cj.row_offset, cj.part, cj.n, cj.d, cj.from_softmax, cb % cj.nbx, cb / cj.nbx);
+        return;
+    }
+    const TileDesc td = tiles[blockIdx.x];
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    G::run(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lcol = G::sub_col();
+    const int j = td.c0 + lcol;
+    const bool jok = j < td.clim;
+    const float sj = sq[min(j, td.clim - 1)];
+    const float bw = bw_ptr[0];
+    const float c2 = -1.4426950408889634f / (4.f * bw);
+    const float wscale = -((td.flags & VGAN_TF_NEG) ? -1.f : 1.f) * 2.f / ((float)n * (float)n * bw);
+    const bool store = (td.flags & VGAN_TF_STORE) && Wh != nullptr;
+    const bool mirror = store && (td.flags & VGAN_TF_MIRROR);
+    float ksum = 0.f;
+    constexpr int LDT = 136, LDM = 129;  // Wt[i][j]: b128 reads, 4*LDT = 32 mod 64 banks; WtT[j][i]: scalar, odd stride
+    lds_f* Wt = (lds_f*)(float*)lds;
+    lds_f* WtT = Wt + 128 * LDT;
+    static_assert((128 * LDT + 128 * LDM) * 4 <= G::kLdsBytes, "epilogue images must fit the staging buffers");
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = G::sub_row(i2, r), i = td.r0 + lrow;
+            const bool ok = jok && (i < td.rlim);
+            const float si = sq[min(i, td.rlim - 1)];
+            const float L = fmaxf(si + sj - 2.f * acc[i2][r], 0.f);
+            const float t = __builtin_amdgcn_exp2f(L * c2);
+            const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+            ksum += ok ? ((t + t2) + (t4 + t8)) + t16 : 0.f;
+            const float w = wscale * (((0.25f * t + 0.5f * t2) + (t4 + 2.f * t8)) + 4.f * t16);
+            if (store) Wt[lrow * LDT + lcol] = w;
+            if (mirror) WtT[lcol * LDM + lrow] = w;
+        }
+    if (store) {  // uniform per workgroup
+        __syncthreads();
+        const int line = threadIdx.x >> 2;  // 128 lines, four threads per line
+        auto emit = [&](const float (&w)[16], long rowo, int c_first, int c_lim) {
+            unsigned hp[8], lp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned short h0, l0, h1, l1;
+                split_bf16(w[2 * e], h0, l0);
+                split_bf16(w[2 * e + 1], h1, l1);
+                hp[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                lp[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+            if (c_first + 15 < c_lim) {
+                uint4* dh = reinterpret_cast<uint4*>(Wh + rowo + c_first);
+                uint4* dl = reinterpret_cast<uint4*>(Wl + rowo + c_first);
+                dh[0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                dh[1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+                dl[0] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+                dl[1] = make_uint4(lp[4], lp[5], lp[6], lp[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (c_first + e < c_lim) {
+                        Wh[rowo + c_first + e] = (unsigned short)(hp[e >> 1] >> (16 * (e & 1)));
+                        Wl[rowo + c_first + e] = (unsigned short)(lp[e >> 1] >> (16 * (e & 1)));
+                    }
+            }
+        };
+        float w[16];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int q16 = 64 * half + 16 * (threadIdx.x & 3);
+            if (td.r0 + line < td.rlim) {  // direct image: row i = r0 + line, columns c0 + q16 ..
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 v = *(const lds_f4*)(Wt + line * LDT + q16 + 4 * e);
+                    w[4 * e] = v[0]; w[4 * e + 1] = v[1]; w[4 * e + 2] = v[2]; w[4 * e + 3] = v[3];
+                }
+                emit(w, (long)(td.r0 + line - wrow0) * ldw, td.c0 + q16, td.clim);
+            }
+            if (mirror && td.c0 + line < td.clim) {  // mirrored image: row j = c0 + line, columns r0 + q16 ..
+#pragma unroll
+                for (int e = 0; e < 16; ++e) w[e] = WtT[line * LDM + q16 + e];
+                emit(w, (long)(td.c0 + line - wrow0) * ldw, td.r0 + q16, td.rlim);
+            }
+        }
+    }
+    ksum = wave_sum(ksum);
+    if (lane == 0) red[wave] = ksum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        reinterpret_cast<float4*>(partial)[blockIdx.x] =
+            make_float4(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])), 0.f, 0.f, 0.f);
+}
+
 // ---- backward: out = 2 (rowsum(W) z - W . Z) * mul, W = Wh + Wl [nr, kn], Z^T = ZTh + ZTl [kp, kn] -------------
 template <int BK>
 __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_kernel(const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
@@ -253,9 +362,9 @@ extern "C" int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, ui
 }
 
 extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
-                                 const int32_t* tiles, int ntiles, uint16_t* Wh, uint16_t* Wl, int ldw, int wrow0, float* partial,
-                                 const float* S, int lds, int from_softmax, int row_offset, uint64_t* colpart, int nrows, int d,
-                                 vgan_stream_t stream) {
+                                 const int32_t* tiles, int ntiles, int tile, uint16_t* Wh, uint16_t* Wl, int ldw, int wrow0,
+                                 float* partial, const float* S, int lds, int from_softmax, int row_offset, uint64_t* colpart,
+                                 int nrows, int d, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Zh && Zl && sq && bw && tiles && partial && n > 0 && ntiles > 0 && kp > 0 && kp % 64 == 0);
     VGAN_CHECK_ARG((Wh == nullptr) == (Wl == nullptr) && (reinterpret_cast<uintptr_t>(partial) & 15) == 0);
     VGAN_CHECK_ARG(aligned16(Zh) && aligned16(Zl) && (Wh == nullptr || (aligned16(Wh) && aligned16(Wl))));
@@ -266,7 +375,11 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
         cj = ColmaxJob{S, reinterpret_cast<unsigned long long*>(colpart), lds, row_offset, nrows, d, from_softmax, (d + 63) / 64};
         extra = cj.nbx * ((nrows + kColChunkRows - 1) / kColChunkRows);
     }
-    if (bf3_bk() == 64)
+    VGAN_CHECK_ARG(tile == 64 || tile == 128);
+    if (tile == 128)
+        hipLaunchKernelGGL(mmd_gram_bf3_big_kernel, dim3(ntiles + extra), dim3(512), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
+                           reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
+    else if (bf3_bk() == 64)
         hipLaunchKernelGGL(mmd_gram_bf3_kernel<64>, dim3(ntiles + extra), dim3(kBlock), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
                            reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
     else

@@ -45,7 +45,7 @@ SIGNATURES = {
     "vgan_colmax": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p]),
     "vgan_mask_from_softmax": (_i, [_p, _i, _p, _i, _i, _i, _p]),
     "vgan_upper_softmax_forward": (_i, [_p, _i, _p, _p, _i, _i, _p]),
-    "vgan_mmd_build_tiles": (_i, [_i, _i, _i, _i, _p, _i]),
+    "vgan_mmd_build_tiles": (_i, [_i, _i, _i, _i, _i, _p, _i]),
     "vgan_mmd_gram": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _p, _p]),
     "vgan_mmd_gram_colmax": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "vgan_mmd_reduce": (_i, [_p, _p, _i, _p, _i, _p]),
@@ -54,7 +54,7 @@ SIGNATURES = {
     "vgan_mmd_finalize_ranks": (_i, [_p, _i, _i, _i, _f, _p, _p, _p, _p, _f, _p, _p]),
     "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p, _p]),
     "vgan_mmd_bf3_prepare": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
-    "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
+    "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p, _p]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
@@ -66,7 +66,7 @@ SIGNATURES = {
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -100,14 +100,14 @@ def check(rc, what=""):
         raise VganHipError(f"{what} failed (code {rc}): {msg}")
 
 
-def build_tiles(n, grad_mode, rank=0, world=1):
+def build_tiles(n, grad_mode, rank=0, world=1, tile=64):
     """Host-side tile table of the Gram kernel as a flat list of int32 (8 per tile)."""
     lib = load()
-    cnt = lib.vgan_mmd_build_tiles(n, grad_mode, rank, world, None, 0)
+    cnt = lib.vgan_mmd_build_tiles(n, grad_mode, rank, world, tile, None, 0)
     if cnt < 0:
         raise VganHipError("vgan_mmd_build_tiles: " + lib.vgan_last_error().decode())
     buf = (ctypes.c_int32 * (cnt * 8))()
-    got = lib.vgan_mmd_build_tiles(n, grad_mode, rank, world, ctypes.cast(buf, ctypes.c_void_p), cnt)
+    got = lib.vgan_mmd_build_tiles(n, grad_mode, rank, world, tile, ctypes.cast(buf, ctypes.c_void_p), cnt)
     if got != cnt:
         raise VganHipError("vgan_mmd_build_tiles: inconsistent tile count")
     return list(buf), cnt

@@ -47,8 +47,8 @@ class HipOps:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ---- host helpers -----------------------------------------------------------------------
-    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None):
-        flat, cnt = _lib.build_tiles(n, grad_mode, rank, world)
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64):
+        flat, cnt = _lib.build_tiles(n, grad_mode, rank, world, tile)
         return torch.tensor(flat, dtype=torch.int32).view(cnt, 8).to(device or "cuda")
 
     def colmax_chunks(self, n):
@@ -221,12 +221,13 @@ class HipOps:
         _lib.check(self.lib.vgan_mmd_bf3_prepare(_ptr(Z), Z.stride(0), int(rows), int(p), _ptr(Zh), _ptr(Zl), Zh.stride(0),
                                                  _ptr(ZTh), _ptr(ZTl), kn, self._stream()), "vgan_mmd_bf3_prepare")
 
-    def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True):
+    def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True,
+                     tile=64):
         ntiles = tiles.shape[0]
         nrows, d = (S.shape if S is not None else (0, 0))
         ldw = Wh.stride(0) if Wh is not None else 0
         _lib.check(self.lib.vgan_mmd_gram_bf3(_ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(sq), int(n), _ptr(bw), _ptr(tiles), ntiles,
-                                              _ptr(Wh), _ptr(Wl), ldw, int(wrow0), _ptr(partial), _ptr(S),
+                                              int(tile), _ptr(Wh), _ptr(Wl), ldw, int(wrow0), _ptr(partial), _ptr(S),
                                               S.stride(0) if S is not None else 0, int(bool(from_softmax)), int(row_offset),
                                               _ptr(colpart), nrows, d, self._stream()), "vgan_mmd_gram_bf3")
 

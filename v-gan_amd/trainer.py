@@ -202,9 +202,18 @@ class NoKLStepEngine:
             self.ZTh, self.ZTl = torch.zeros(self.kp, self.kn, **i16), torch.zeros(self.kp, self.kn, **i16)
             self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
-        self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev)
+        # Gram tile edge: the split-bf16 Gram has a 128x128 variant (half the L2 -> LDS bytes per flop, one 512-thread
+        # workgroup per CU).  Measured: c5 330 vs 273 TFLOP/s algorithmic, c3 (136 tiles of 128) no gain (26.3 vs 25.6 us),
+        # so it is used once its table fills the chip twice over and the row shard is a whole number of tiles.
+        self.gram_tile = 64
+        want = os.environ.get("VGAN_GRAM_TILE", "auto")
+        if self.bf3 and nl % 128 == 0 and want in ("auto", "128"):
+            if want == "128" or len(ops.build_tiles(n, 1, rank, world, device=self.dev, tile=128)) >= 512:
+                self.gram_tile = 128
+        self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile)
         # the first-call bandwidth needs sum(L) over ALL pairs: computed by every rank from the full table (no collective)
-        self.tiles_cal = self.tiles if world == 1 else ops.build_tiles(n, 0, 0, 1, device=self.dev)
+        # (the calibration launch is the fp32 kernel: 64-wide tiles)
+        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
         self.partial = torch.zeros(max(self.tiles.shape[0], self.tiles_cal.shape[0]), 4, **f32)
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
@@ -351,7 +360,7 @@ class NoKLStepEngine:
             ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
         if bf3:
             ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
-                             self.colpart, True)
+                             self.colpart, True, tile=self.gram_tile)
         else:
             ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, 0,
                                 self.colpart, True)
