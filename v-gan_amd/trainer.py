@@ -38,7 +38,9 @@ single-GPU step time at c3.)
 
 Measured and rejected (MI355X, ROCm 7.2, c3): a fork/join HIP graph (XX tiles and weight-gradient GEMMs
 on side streams) replays SLOWER than the plain chain (357 vs 313 us/step): each cross-stream edge costs
-more than the overlap returns.
+more than the overlap returns.  Re-measured on the final step with ONLY the X-X block sums (which feed the reported
+loss, never a gradient) on a side stream that starts after the mask backward and joins at the end of the step:
+161 vs 138 us/step, although dropping those tiles outright would save 7 us.
 """
 import os
 
