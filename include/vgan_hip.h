@@ -296,6 +296,20 @@ int vgan_adadelta_step_packed(float* p, const int32_t* pmap, const float* g_pack
 int vgan_mse(const float* a, int lda, const float* b, int ldb, int n, int d, float scale,
              float* out, int accumulate, vgan_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Myopicity two-sample test  (check_if_myopic, src/vgan.py:384-431 -> torch-two-sample's MMDStatistic
+ * with ret_matrix=True and its permutation p-value; that dependency is absent and unpinned, the algorithm
+ * is restated in oracle/vgan_oracle.py: PARITY UNPINNED against the dependency).
+ * vgan_rbf_kernel_matrix: K[i,j] = exp(-alpha |z_i - z_j|^2) for the m rows of Z ([m, p], sq = squared row
+ * norms), K[i,i] = 1.   vgan_rows_dot: out[r] = sum_c A[r,c] * B[r*ldb + c] in float64 (ldb = 0 broadcasts
+ * one row of B) -- with T = Ut . K (vgan_gemm_grouped) this gives u^T K u and u^T K 1 for every 0/1
+ * assignment row u of Ut, from which the host forms the permutation statistics.
+ * ------------------------------------------------------------------------------------------- */
+int vgan_rbf_kernel_matrix(const float* Z, int ldz, int m, int p, const float* sq, float alpha, float* K, int ldk,
+                           vgan_stream_t stream);
+int vgan_rows_dot(const float* A, int lda, const float* B, int ldb, double* out, int rows, int cols,
+                  vgan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -286,3 +286,40 @@ def synthetic_generator_params(d: int, seed: int = 0, dtype=np.float32):
         params.append(rng.uniform(-k, k, size=(out, inp)).astype(dtype))
         params.append(rng.uniform(-k, k, size=(out,)).astype(dtype))
     return params
+
+
+# ---- myopicity two-sample test (check_if_myopic, src/vgan.py:384-431) ------------------------------------------------
+# The reference delegates to torch-two-sample (josipd/torch-two-sample, unpinned, not vendored, not installed here):
+# MMDStatistic(n1, n2)(x, y, alphas=[a], ret_matrix=True) and .pval(matrix, n_permutations=1000).  The functions below
+# restate that package's published algorithm; nothing in /root/reference pins them: PARITY UNPINNED.
+def two_sample_kernel_matrix(X, Y, alpha):
+    """exp(-alpha * |z_i - z_j|^2) over the pooled sample [X ; Y] (MMDStatistic.__call__ with one alpha)."""
+    Z = np.vstack([X, Y]).astype(np.float64)
+    L = squared_distances(Z)
+    K = np.exp(-float(alpha) * L)
+    np.fill_diagonal(K, 1.0)
+    return K
+
+
+def two_sample_statistic(K, group1):
+    """Permutation statistic of torch-two-sample's permutation_test_mat for one assignment (group1: bool [m]):
+    sum_{i<=j} (K_ij + K_ji) * a(i, j), a = a00 / a11 inside a group, a01 across, with a00 = 1/(n1(n1-1)),
+    a11 = 1/(n2(n2-1)), a01 = -1/(n1 n2).  In closed form: a00 (u'Ku + tr_u) + a11 (v'Kv + tr_v) + 2 a01 u'Kv."""
+    u = np.asarray(group1, dtype=np.float64)
+    v = 1.0 - u
+    n1, n2 = u.sum(), v.sum()
+    a00, a11, a01 = 1.0 / (n1 * (n1 - 1)), 1.0 / (n2 * (n2 - 1)), -1.0 / (n1 * n2)
+    Ku, Kv = K @ u, K @ v
+    dg = np.diag(K)
+    return a00 * (u @ Ku + dg @ u) + a11 * (v @ Kv + dg @ v) + 2.0 * a01 * (u @ Kv)
+
+
+def two_sample_pvalue(K, n1, assignments):
+    """p = #{permuted statistic >= observed} / #permutations; `assignments` [P, m] bool are the shuffled group-1
+    indicators (the package shuffles with numpy's global generator; callers pass theirs)."""
+    m = K.shape[0]
+    observed = np.zeros(m, dtype=bool)
+    observed[:n1] = True
+    s0 = two_sample_statistic(K, observed)
+    larger = sum(1 for a in assignments if s0 <= two_sample_statistic(K, a))
+    return larger / float(len(assignments)), s0

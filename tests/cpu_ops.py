@@ -307,6 +307,18 @@ class CpuOps:
         for (_, _, _, C), r in zip(problems, outs):
             C.copy_(torch.as_tensor(r))
 
+    def rbf_kernel_matrix(self, Z, sq, alpha, K):
+        z = _np(Z).astype(np.float64)
+        s = (z * z).sum(1)
+        L = np.maximum(s[:, None] + s[None, :] - 2.0 * z @ z.T, 0.0)
+        k = np.exp(-float(alpha) * L)
+        np.fill_diagonal(k, 1.0)
+        K[:, :z.shape[0]].copy_(torch.as_tensor(k))
+
+    def rows_dot(self, A, B, out, broadcast_b=False):
+        a, b = _np(A).astype(np.float64), _np(B).astype(np.float64)
+        out[:a.shape[0]].copy_(torch.as_tensor((a * (b.reshape(1, -1) if broadcast_b else b)).sum(1)))
+
     # ---- optimiser / noise
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         if nslabs > 1:

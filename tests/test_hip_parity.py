@@ -7,6 +7,8 @@ Tolerances (fp32 path, stated per level as SURVEY.md section 7 asks):
   gradients    <= 1e-3 of the tensor's max magnitude (fp32 Gram cancellation), typically ~1e-5
   masks        Hamming distance 0 on the pinned c1 trajectory
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -779,3 +781,38 @@ def test_gram_bf3_tile128_equals_tile64(ops, n, d, mode):
     wa, wb = val(a[1], a[2]), val(b[1], b[2])
     assert float((wa - wb).abs().max()) <= 5e-5 * float(wa.abs().max())
     assert float((a[1] != b[1]).double().mean()) < 1e-3  # hi halves differ only where w sits on a bf16 rounding boundary
+
+
+def test_two_sample_kernels_and_check_if_myopic(ops):
+    """vgan_rbf_kernel_matrix / vgan_rows_dot against numpy, and check_if_myopic end to end on the GPU against the oracle's
+    restatement of torch-two-sample (parity unpinned against that absent dependency)."""
+    rng = np.random.default_rng(8)
+    Z = rng.normal(size=(150, 28)).astype(np.float32) * 0.5
+    Zd = dev(Z)
+    sq = torch.empty(150, device="cuda")
+    ops.row_sqnorm(Zd, sq, 28)
+    K = torch.zeros(152, 152, device="cuda")
+    ops.rbf_kernel_matrix(Zd, sq, 0.3, K[:150])
+    want = orc.two_sample_kernel_matrix(Z[:75], Z[75:], 0.3)
+    np.testing.assert_allclose(host(K)[:150, :150], want, rtol=0, atol=2e-6)
+    assert float(K[:, 150:].abs().max()) == 0.0
+    A, B = dev(rng.normal(size=(37, 152)).astype(np.float32)), dev(rng.normal(size=(37, 152)).astype(np.float32))
+    out = torch.empty(37, dtype=torch.float64, device="cuda")
+    ops.rows_dot(A, B, out)
+    np.testing.assert_allclose(host(out), (host(A).astype(np.float64) * host(B)).sum(1), rtol=1e-12)
+    ops.rows_dot(A, B[3:4], out, broadcast_b=True)
+    np.testing.assert_allclose(host(out), (host(A).astype(np.float64) * host(B)[3]).sum(1), rtol=1e-12)
+
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_logic import _myopic_reference
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    g = load_golden("f3_traj_c1.npz")
+    model = VGAN_no_kl(batch_size=128, epochs=3, seed=777)
+    model.verbose = False
+    model.fit(g["data"])
+    df = model.check_if_myopic(g["data"], bandwidth=0.5, count=200, n_permutations=300)
+    want = _myopic_reference(model, g["data"], [0.5], 200, 300)
+    np.testing.assert_allclose(df.to_numpy()[0].astype(float), want, rtol=0, atol=2.0 / 300)

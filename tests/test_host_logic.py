@@ -108,8 +108,8 @@ def test_fit_loop_reproduces_reference_run_on_cpu_provider():
     assert float(MMDLossConstrained(weight=1).kernel.bandwidth) == pytest.approx(float(g["bw"]), rel=1e-5)
     model.approx_subspace_dist()
     assert model.subspaces.shape[1] == 20 and abs(model.proba.sum() - 1) < 1e-12
-    with pytest.raises(NotImplementedError):
-        model.check_if_myopic(g["data"])
+    with pytest.raises(AssertionError):  # the reference's only explicit check (src/vgan.py:398)
+        model.check_if_myopic(g["data"][:100], count=500)
 
 
 def test_batch_size_clamp_and_history_shape():
@@ -123,3 +123,52 @@ def test_batch_size_clamp_and_history_shape():
     assert model.batch_size == 96 and len(model.train_history["generator_loss"]) == 3
     assert model.get_params()["generator optimizer"] == "Adadelta"
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
+def _myopic_reference(model, data, bandwidths, count, n_perm):
+    """p-values of oracle.two_sample_pvalue on exactly the samples / permutations check_if_myopic draws."""
+    x = np.asarray(data, dtype=np.float64)
+    norms = np.sqrt((x * x).sum(axis=0))
+    x = x / np.where(norms == 0.0, 1.0, norms)
+    rng = np.random.default_rng(model.seed)
+    rows = rng.choice(x.shape[0], size=count, replace=False)
+    xs = x[rows].astype(np.float32)
+    u = model.generate_subspaces(count).cpu().numpy()
+    ux = np.where(u, xs, xs.mean(axis=0, keepdims=True, dtype=np.float32)).astype(np.float32)
+    m = 2 * count
+    assign = np.zeros((n_perm, m), dtype=bool)
+    for q in range(n_perm):
+        assign[q, rng.permutation(m)[:count]] = True
+    out = []
+    for alpha in sorted(bandwidths) + [float(model.bandwidth)]:
+        K = orc.two_sample_kernel_matrix(xs, ux, alpha)
+        out.append(orc.two_sample_pvalue(K, count, assign)[0])
+    return out
+
+
+def test_check_if_myopic_matches_stated_definition_on_cpu_provider():
+    """check_if_myopic (src/vgan.py:384-431): host logic + provider calls against the oracle's restatement of
+    torch-two-sample's statistic and permutation p-value (parity unpinned against that absent dependency)."""
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    g = load_golden("f3_traj_c1.npz")
+    model = VGAN_no_kl(batch_size=128, epochs=2, seed=777)
+    model._ops_override = CpuOps()
+    model.device = torch.device("cpu")
+    model.noise_source = "host"
+    model.verbose = False
+    model.fit(g["data"])
+    df = model.check_if_myopic(g["data"], bandwidth=[1.0, 0.01], count=90, n_permutations=120)
+    assert list(df.columns) == [0.01, 1.0, "recommended bandwidth"] and list(df.index) == ["p-val"]
+    want = _myopic_reference(model, g["data"], [1.0, 0.01], 90, 120)
+    np.testing.assert_allclose(df.to_numpy()[0].astype(float), want, rtol=0, atol=1.0 / 120 + 1e-12)
+    # a sample against itself shifted far away is rejected; against an identical copy it is not
+    K = orc.two_sample_kernel_matrix(g["data"][:60], g["data"][:60] + 3.0, 0.05)
+    rng = np.random.default_rng(0)
+    assign = np.zeros((200, 120), dtype=bool)
+    for q in range(200):
+        assign[q, rng.permutation(120)[:60]] = True
+    assert orc.two_sample_pvalue(K, 60, assign)[0] == 0.0
+    K = orc.two_sample_kernel_matrix(g["data"][:60], g["data"][60:120], 0.05)
+    assert orc.two_sample_pvalue(K, 60, assign)[0] > 0.05

@@ -260,6 +260,21 @@ class HipOps:
             q.lda, q.ldb, q.ldc = A.stride(0), B.stride(0), C.stride(0)
         _lib.check(self.lib.vgan_gemm_grouped(arr, len(problems), self._stream()), "vgan_gemm_grouped")
 
+    # ---- myopicity two-sample test -----------------------------------------------------------------
+    def rbf_kernel_matrix(self, Z, sq, alpha, K):
+        _mat(Z, "Z"), _mat(K, "K")
+        m, p = Z.shape
+        _lib.check(self.lib.vgan_rbf_kernel_matrix(_ptr(Z), Z.stride(0), m, p, _ptr(sq), float(alpha), _ptr(K), K.stride(0),
+                                                   self._stream()), "vgan_rbf_kernel_matrix")
+
+    def rows_dot(self, A, B, out, broadcast_b=False):
+        """out[r] = <A[r], B[r]> (float64); broadcast_b: B is one row used for every r."""
+        _mat(A, "A")
+        rows, cols = A.shape
+        assert out.dtype == torch.float64 and out.numel() >= rows
+        ldb = 0 if broadcast_b else B.stride(0)
+        _lib.check(self.lib.vgan_rows_dot(_ptr(A), A.stride(0), _ptr(B), ldb, _ptr(out), rows, cols, self._stream()), "vgan_rows_dot")
+
     # ---- optimiser / noise / misc ----------------------------------------------------------------
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         """nslabs > 1: `g` is slab 0 of split-K gradient slabs `slab_stride` apart, summed inside the kernel."""

@@ -158,10 +158,70 @@ class _RunFolder:
         self.subspaces = unique_subspaces
         self.proba = proba / proba.sum()
 
-    def check_if_myopic(self, x_data, bandwidth=0.01, count=500):
-        raise NotImplementedError(
-            "check_if_myopic (src/vgan.py:384-431) rests on torch-two-sample's permutation test, which is not part "
-            "of the reference checkout and is unpinned; it is outside this build's hot-path scope (SURVEY.md 8f rank 2)")
+    def check_if_myopic(self, x_data, bandwidth=0.01, count=500, n_permutations=1000):
+        """src/vgan.py:384-431: two-sample (MMD, permutation) test of P(x) against P(u * x + mean(x) * ~u), once per given
+        bandwidth and once with the recommended one; returns a DataFrame of p-values.
+
+        The reference delegates the statistic and the permutation p-value to torch-two-sample, which is neither vendored
+        nor pinned; the algorithm used here is that package's published one as restated in
+        oracle/vgan_oracle.py -- parity unpinned.  The kernel matrix, the P x m by m x m product and the per-permutation
+        dot products run on the GPU; random choices (row sample, permutations) come from numpy's Generator seeded with
+        ``self.seed`` instead of numpy's global state."""
+        import pandas as pd
+        from .modules import MMDLossConstrained
+        x_data = np.asarray(x_data, dtype=np.float64)
+        assert count <= x_data.shape[0], "Selected 'count' is greater than the number of samples in the dataset"
+        ops, dev = self._ops(), self.device
+        rng = np.random.default_rng(self.seed)
+        norms = np.sqrt((x_data * x_data).sum(axis=0))          # sklearn.preprocessing.normalize(x, axis=0), L2
+        x_data = x_data / np.where(norms == 0.0, 1.0, norms)
+        rows = rng.choice(x_data.shape[0], size=count, replace=False)
+        x_sample = torch.as_tensor(x_data[rows], dtype=torch.float32).to(dev)
+        u = self.generate_subspaces(count)
+        ux_sample = torch.where(u, x_sample, x_sample.mean(dim=0, keepdim=True).expand_as(x_sample)).contiguous()
+        if isinstance(bandwidth, float):
+            bandwidth = [bandwidth]
+        bandwidth = sorted(bandwidth)
+        if not hasattr(self, "bandwidth") or self.bandwidth is None:
+            mmd_loss = MMDLossConstrained(0)
+            mmd_loss.forward(x_sample, ux_sample, u * 1.0)
+            self.bandwidth = mmd_loss.bandwidth
+        rec = float(self.bandwidth.item()) if torch.is_tensor(self.bandwidth) else float(self.bandwidth)
+
+        m, P = 2 * count, int(n_permutations)
+        dp = (x_sample.shape[1] + 3) // 4 * 4
+        Z = torch.zeros(m, dp, dtype=torch.float32, device=dev)
+        Z[:count, :x_sample.shape[1]] = x_sample
+        Z[count:, :x_sample.shape[1]] = ux_sample
+        sq = torch.empty(m, dtype=torch.float32, device=dev)
+        ops.row_sqnorm(Z, sq, dp)
+        mp = (m + 3) // 4 * 4
+        # assignment rows: 0 = observed (first `count` in group 1), 1..P = shuffles, P+1 = all ones (gives r = 1'K)
+        Ut = np.zeros((P + 2, mp), dtype=np.float32)
+        Ut[0, :count] = 1.0
+        for q in range(1, P + 1):
+            Ut[q, rng.permutation(m)[:count]] = 1.0
+        Ut[P + 1, :m] = 1.0
+        Ut = torch.as_tensor(Ut).to(dev)
+        K = torch.zeros(mp, mp, dtype=torch.float32, device=dev)
+        T = torch.empty(P + 2, mp, dtype=torch.float32, device=dev)
+        a = torch.empty(P + 2, dtype=torch.float64, device=dev)
+        b = torch.empty(P + 2, dtype=torch.float64, device=dev)
+        n1 = n2 = float(count)
+        a00, a11, a01 = 1.0 / (n1 * (n1 - 1)), 1.0 / (n2 * (n2 - 1)), -1.0 / (n1 * n2)
+        results = []
+        for alpha in list(bandwidth) + [rec]:
+            ops.rbf_kernel_matrix(Z, sq, alpha, K[:m])          # rows/cols >= m stay zero
+            ops.gemm_grouped([("NN", Ut, K, T)])                # T = Ut . K
+            ops.rows_dot(Ut, T, a)                              # u'Ku
+            ops.rows_dot(Ut, T[P + 1:P + 2], b, broadcast_b=True)  # u'K1
+            ah, bh = a.cpu().numpy(), b.cpu().numpy()
+            total = ah[P + 1]
+            uKv = bh - ah
+            vKv = total - 2.0 * bh + ah
+            stat = a00 * (ah + n1) + a11 * (vKv + n2) + 2.0 * a01 * uKv   # K_ii = 1
+            results.append(float((stat[0] <= stat[1:P + 1]).sum()) / P)
+        return pd.DataFrame([results], columns=list(bandwidth) + ["recommended bandwidth"], index=["p-val"])
 
     def _save_run(self, generator, detector_too):
         path_to_directory = Path(self.path_to_directory)
