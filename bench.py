@@ -47,6 +47,9 @@ def parse():
                     help="untimed steps run right after graph capture so that the GPU clock has ramped (DVFS) before the "
                          "W warm-up steps; a fit runs for minutes, so the ramped state is the representative one")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--path", choices=["nokl", "kl"], default="nokl",
+                    help="nokl: the metric's VGAN_no_kl step (default); kl: VGAN.fit's detector step (SURVEY 8a10), an extra "
+                         "informational line -- eager launches, one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3"], default=None,
@@ -173,11 +176,45 @@ def gpu_first_loss(params, X, z, **engine_kw):
     return float(eng.loss)
 
 
+def bench_kl(args):
+    """VGAN.fit detector steps (kl_trainer.KLStepEngine) at the selected workload: steps/s of eager launches."""
+    import vgan_amd
+    from vgan_amd import synth
+    from vgan_amd.kl_trainer import KLStepEngine
+    from vgan_amd.ops import HipOps
+    torch.cuda.set_device(0)
+    torch.manual_seed(777)
+    data = torch.as_tensor(synth.synthetic_dataset(CONFIG)).cuda()
+    L = synth.latent_size(D_FEAT)
+    gen = vgan_amd.Generator_big(L, D_FEAT)
+    det = vgan_amd.Detector(L, D_FEAT, vgan_amd.Encoder, vgan_amd.Decoder)
+    for mod in (gen, det):
+        for q in mod.parameters():
+            q.data.normal_(0.0, 0.1)
+    eng = KLStepEngine(HipOps(), gen.cuda(), det.cuda(), data, N_BATCH, 0.007, 0.04, 1.0)
+    idx = torch.randperm(data.shape[0])[:N_BATCH].cuda()
+    z = torch.randn(N_BATCH, L).cuda()
+    steps = min(args.steps, 500)
+    for _ in range(20):
+        eng.detector_step(idx, z, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.detector_step(idx, z, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": f"VGAN.fit detector steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": steps / dt, "unit": "steps/s",
+                      "n_gpus": 1, "steps": steps, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "dtype": "f32",
+                      "data": "synthetic", "config": {"workload": WORKLOAD + " [VGAN.fit detector step, eager launches]"}}), flush=True)
+
+
 def main():
     global N_BATCH, D_FEAT, EPOCH_BATCHES, CONFIG, WORKLOAD
     args = parse()
     CONFIG = args.workload
     N_BATCH, D_FEAT, EPOCH_BATCHES, WORKLOAD = WORKLOADS[CONFIG]
+    if args.path == "kl":
+        return bench_kl(args)
     if CONFIG != "c3":
         args.steps, args.warmup = min(args.steps, 200), min(args.warmup, 8)
         args.no_cpu_baseline = args.no_cpu_baseline or CONFIG == "c5"  # N = 16384: ~17 GB and ~15 s per CPU step

@@ -292,9 +292,16 @@ int vgan_adadelta_step_packed(float* p, const int32_t* pmap, const float* g_pack
                               uint64_t seed, const uint64_t* step_counter, vgan_stream_t stream);
 
 /* sum of squared differences: out[0] (+)= scale * sum((a-b)^2)  -- `__distance(x,y,'L2')`,
- * src/vgan.py:58-59, and its gradient  ga (+)= gscale*(a-b), gb (+)= -gscale*(a-b). */
+ * src/vgan.py:58-59 (one workgroup; for reporting-sized inputs). */
 int vgan_mse(const float* a, int lda, const float* b, int ldb, int n, int d, float scale,
              float* out, int accumulate, vgan_stream_t stream);
+
+/* The same term with its gradient, for VGAN.fit's detector loss (src/vgan.py:276-277): one pass over [n, d],
+ * part[b] (b < ceil(n/4)) = float64 partial sums of (pred - target)^2, g = gscale * (pred - target).
+ * vgan_sum_f64 folds such partials: out[0] (+)= scale * sum(in[0..count)), fixed order. */
+int vgan_mse_grad(const float* target, int ldt, const float* pred, int ldp, int n, int d, float gscale,
+                  double* part, float* g, int ldg, vgan_stream_t stream);
+int vgan_sum_f64(const double* in, int count, double scale, float* out, int accumulate, vgan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Myopicity two-sample test  (check_if_myopic, src/vgan.py:384-431 -> torch-two-sample's MMDStatistic

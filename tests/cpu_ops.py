@@ -307,6 +307,19 @@ class CpuOps:
         for (_, _, _, C), r in zip(problems, outs):
             C.copy_(torch.as_tensor(r))
 
+    def mse_grad(self, target, pred, gscale, part, g):
+        n, d = pred.shape
+        df = _np(pred)[:, :d].astype(np.float64) - _np(target)[:, :d].astype(np.float64)
+        rows = (df * df).sum(1)
+        pad = np.zeros((n + 3) // 4 * 4)
+        pad[:n] = rows
+        part[:(n + 3) // 4].copy_(torch.as_tensor(pad.reshape(-1, 4).sum(1)))
+        g[:, :d].copy_(torch.as_tensor(float(gscale) * df))
+
+    def sum_f64(self, src, count, scale, out, accumulate=False):
+        v = float(_np(src)[:count].sum() * scale)
+        out[0] = (float(out[0]) if accumulate else 0.0) + v
+
     def rbf_kernel_matrix(self, Z, sq, alpha, K):
         z = _np(Z).astype(np.float64)
         s = (z * z).sum(1)

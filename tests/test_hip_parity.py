@@ -816,3 +816,43 @@ def test_two_sample_kernels_and_check_if_myopic(ops):
     df = model.check_if_myopic(g["data"], bandwidth=0.5, count=200, n_permutations=300)
     want = _myopic_reference(model, g["data"], [0.5], 200, 300)
     np.testing.assert_allclose(df.to_numpy()[0].astype(float), want, rtol=0, atol=2.0 / 300)
+
+
+@pytest.mark.parametrize("n,d", [(256, 166), (192, 70)])
+def test_kl_step_engine_hip_vs_cpu_provider(ops, n, d):
+    """VGAN.fit's step engine (kl_trainer.KLStepEngine) at musk-like sizes: the HIP kernels against the float64 numpy
+    provider of tests/cpu_ops.py on identical parameters, batches and noise -- two detector steps (encoder trainable, then
+    frozen), one generator-phase step: loss terms, bandwidth and every detector parameter."""
+    from cpu_ops import CpuOps
+    from vgan_amd.kl_trainer import KLStepEngine
+    from vgan_amd.modules import Decoder, Detector, Encoder, Generator_big
+    rng = np.random.default_rng(n + d)
+    L = orc.latent_size(d)
+    data = (rng.normal(size=(3 * n, d)) * rng.uniform(0.5, 1.5, size=(1, d))).astype(np.float32)
+    torch.manual_seed(5)
+    gen0, det0 = Generator_big(L, d), Detector(L, d, Encoder, Decoder)
+    for mod in (gen0, det0):
+        for q in mod.parameters():
+            q.data.normal_(0.0, 0.1)
+    state_g, state_d = {k: v.clone() for k, v in gen0.state_dict().items()}, {k: v.clone() for k, v in det0.state_dict().items()}
+    res = {}
+    for name, provider, device in (("hip", ops, "cuda"), ("cpu", CpuOps(), "cpu")):
+        gen, det = Generator_big(L, d), Detector(L, d, Encoder, Decoder)
+        gen.load_state_dict(state_g), det.load_state_dict(state_d)
+        gen, det = gen.to(device), det.to(device)
+        eng = KLStepEngine(provider, gen, det, torch.as_tensor(data).to(device), n, lr_D=0.007, weight_decay=0.04, penalty_weight=10.0)
+        r2 = np.random.default_rng(1)
+        sums = []
+        for step, (kind, enc_train) in enumerate([("d", True), ("d", False), ("g", False)]):
+            idx = torch.as_tensor(r2.permutation(3 * n)[:n])
+            z = torch.as_tensor(r2.normal(size=(n, L)).astype(np.float32))
+            if kind == "d":
+                eng.detector_step(idx, z, train_encoder=enc_train)
+            else:
+                eng.generator_phase_step(idx, z)
+            sums.append(eng.epoch_sums())
+        res[name] = (np.array(sums), float(eng.bw), [q.detach().cpu().numpy().copy() for q in det.parameters()])
+    np.testing.assert_allclose(res["hip"][0], res["cpu"][0], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(res["hip"][1], res["cpu"][1], rtol=1e-5)
+    for a, b in zip(res["hip"][2], res["cpu"][2]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)

@@ -172,3 +172,29 @@ def test_check_if_myopic_matches_stated_definition_on_cpu_provider():
     assert orc.two_sample_pvalue(K, 60, assign)[0] == 0.0
     K = orc.two_sample_kernel_matrix(g["data"][:60], g["data"][60:120], 0.05)
     assert orc.two_sample_pvalue(K, 60, assign)[0] > 0.05
+
+
+def test_vgan_kl_fit_reproduces_reference_run_on_cpu_provider():
+    """VGAN.fit (kernel learning; step engine of v-gan_amd/kl_trainer.py, explicit forward/backward, no autograd) against
+    the reference's own 12-epoch run (fixture f4): both loss histories, the bandwidth, the never-trained generator, the
+    detector parameters and their requires_grad flags (encoder-freeze quirk)."""
+    from src.vgan import VGAN
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    g = load_golden("f4_kl_c1.npz")
+    model = VGAN(batch_size=128, epochs=12)
+    model._ops_override = CpuOps()
+    model.device = torch.device("cpu")
+    model.verbose = False
+    model.fit(g["data"])
+    gl, dl = np.array(model.train_history["generator_loss"]), np.array(model.train_history["detector_loss"])
+    assert np.isnan(gl[0]) and np.isnan(g["generator_loss"][0])
+    np.testing.assert_allclose(gl[1:], g["generator_loss"][1:], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(dl, g["detector_loss"], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(float(model.bandwidth), float(g["bw"]), rtol=1e-3)
+    for i, q in enumerate(model.generator.parameters()):
+        assert np.array_equal(q.detach().numpy(), g[f"genT_{i}"])
+    for i, q in enumerate(model.detector.parameters()):
+        np.testing.assert_allclose(q.detach().numpy(), g[f"detT_{i}"], rtol=0, atol=1e-3)
+        assert bool(q.requires_grad) == bool(g[f"detT_rg_{i}"])
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None

@@ -194,6 +194,45 @@ __global__ __launch_bounds__(kBlock) void mse_kernel(const float* __restrict__ a
     }
 }
 
+// Squared-error term of VGAN.fit's detector loss, value and gradient in one pass (src/vgan.py:58-59, :276-277):
+// part[block] = sum over the block's rows of (pred - target)^2 (float64), g = gscale * (pred - target).
+__global__ __launch_bounds__(kBlock) void mse_grad_kernel(const float* __restrict__ target, int ldt, const float* __restrict__ pred,
+                                                         int ldp, int n, int d, float gscale, double* __restrict__ part,
+                                                         float* __restrict__ g, int ldg) {
+    __shared__ double red[4];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double s = 0.0;
+    if (row < n) {
+        const float* t = target + (long)row * ldt;
+        const float* q = pred + (long)row * ldp;
+        float* o = g + (long)row * ldg;
+        for (int j = threadIdx.x & 63; j < d; j += 64) {
+            const float df = q[j] - t[j];
+            s += (double)df * (double)df;
+            o[j] = gscale * df;
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] (+)= scale * sum(in[0..count))  -- one workgroup, fixed summation order
+__global__ __launch_bounds__(kBlock) void sum_f64_kernel(const double* __restrict__ in, int count, double scale, float* __restrict__ out,
+                                                        int accumulate) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) s += in[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(((red[0] + red[1]) + (red[2] + red[3])) * scale);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
 }  // namespace vgan
 
 using namespace vgan;
@@ -259,6 +298,22 @@ extern "C" int vgan_mse(const float* a, int lda, const float* b, int ldb, int n,
                         vgan_stream_t stream) {
     VGAN_CHECK_ARG(a && b && out && n > 0 && d > 0 && lda >= d && ldb >= d);
     hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, a, lda, b, ldb, n, d, scale, out, accumulate);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mse_grad(const float* target, int ldt, const float* pred, int ldp, int n, int d, float gscale, double* part,
+                             float* g, int ldg, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(target && pred && part && g && n > 0 && d > 0 && ldt >= d && ldp >= d && ldg >= d);
+    hipLaunchKernelGGL(mse_grad_kernel, dim3((n + 3) / 4), dim3(kBlock), 0, (hipStream_t)stream, target, ldt, pred, ldp, n, d, gscale, part,
+                       g, ldg);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_sum_f64(const double* in, int count, double scale, float* out, int accumulate, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(in && out && count > 0);
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, in, count, scale, out, accumulate);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -260,6 +260,19 @@ class HipOps:
             q.lda, q.ldb, q.ldc = A.stride(0), B.stride(0), C.stride(0)
         _lib.check(self.lib.vgan_gemm_grouped(arr, len(problems), self._stream()), "vgan_gemm_grouped")
 
+    def mse_grad(self, target, pred, gscale, part, g):
+        """part[ceil(n/4)] (float64) = partial sums of (pred - target)^2; g = gscale * (pred - target)."""
+        _mat(target, "target"), _mat(pred, "pred"), _mat(g, "g")
+        n, d = pred.shape
+        assert part.dtype == torch.float64 and part.numel() >= (n + 3) // 4
+        _lib.check(self.lib.vgan_mse_grad(_ptr(target), target.stride(0), _ptr(pred), pred.stride(0), n, d, float(gscale), _ptr(part),
+                                          _ptr(g), g.stride(0), self._stream()), "vgan_mse_grad")
+
+    def sum_f64(self, src, count, scale, out, accumulate=False):
+        assert src.dtype == torch.float64
+        _lib.check(self.lib.vgan_sum_f64(_ptr(src), int(count), float(scale), _ptr(out), int(bool(accumulate)), self._stream()),
+                   "vgan_sum_f64")
+
     # ---- myopicity two-sample test -----------------------------------------------------------------
     def rbf_kernel_matrix(self, Z, sq, alpha, K):
         _mat(Z, "Z"), _mat(K, "K")

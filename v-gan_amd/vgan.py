@@ -14,6 +14,7 @@ from torch.utils.data import DataLoader
 
 from .modules import Decoder, Detector, Encoder, Generator_big, MMDLossConstrained
 from .ops import default_ops
+from .kl_trainer import KLStepEngine
 from .trainer import NoKLStepEngine
 
 
@@ -387,64 +388,57 @@ class VGAN(_RunFolder):
         detector.apply(self._weights_init)
         generator, detector = generator.to(device), detector.to(device)
 
-        gen_optimizer = torch.optim.Adadelta(generator.parameters(), lr=self.lr_G, weight_decay=self.weight_decay)
-        det_optimizer = torch.optim.Adadelta(detector.parameters(), lr=self.lr_D, weight_decay=self.weight_decay)
-        self.generator_optimizer = gen_optimizer.__class__.__name__
-        self.detector_optimizer = det_optimizer.__class__.__name__
+        # the reference builds torch.optim.Adadelta for both networks (src/vgan.py:206-209); the generator's never sees a
+        # gradient (see below) and the detector's update runs in the step engine's Adadelta kernel
+        self.generator_optimizer = "Adadelta"
+        self.detector_optimizer = "Adadelta"
         loss_function = MMDLossConstrained(weight=self.temperature)
 
         data = torch.as_tensor(X).to(device=device, dtype=torch.float32).contiguous()
         batch_number = train_size // self.batch_size
+        engine = KLStepEngine(self._ops(), generator, detector, data, self.batch_size, self.lr_D, self.weight_decay,
+                              loss_function.weight)
+        self._engine = engine
+        if loss_function.kernel.bandwidth is not None:  # process-wide RBF already calibrated (reference quirk)
+            engine.set_bandwidth(float(loss_function.kernel.bandwidth))
         iternum_d = iternum_g = 1
         detector_loss = generator_loss = np.nan
-        mse = lambda a, b: (a - b).pow(2).mean()  # __distance(x, y, 'L2'), src/vgan.py:58-59
+        encoder_trainable = True
+
+        def sync_bandwidth():
+            if loss_function.kernel.bandwidth is None:
+                loss_function.kernel.bandwidth = engine.bw.view(())
+            loss_function.bandwidth = loss_function.kernel.bandwidth
+            self.bandwidth = loss_function.bandwidth
 
         for epoch in range(self.epochs):
             if self.verbose:
                 print(f"\rEpoch {epoch} of {self.epochs}")
             noise_tensor = torch.Tensor(self.batch_size, latent_size)
             if iternum_d <= self.iternum_d:
-                acc = torch.zeros((), device=device)
                 for idx in epoch_batches(train_size, self.batch_size):
-                    batch = data[idx.to(device)]
-                    for p in detector.decoder.parameters():
+                    for p in detector.decoder.parameters():  # src/vgan.py:257-258
                         p.requires_grad = True
-                    batch_enc, batch_dec = detector(batch)
-                    with torch.no_grad():
-                        fake_subspaces = generator(noise_tensor.normal_().to(device)).clone().detach()
-                    projected = fake_subspaces * batch
-                    projected_enc, projected_dec = detector(projected)
-                    det_optimizer.zero_grad()
-                    batch_loss_D = -1 * (loss_function(batch_enc, projected_enc, fake_subspaces)
-                                         - .1 * mse(batch, batch_dec) - .1 * mse(projected, projected_dec))
-                    self.bandwidth = loss_function.bandwidth
-                    batch_loss_D.backward()
-                    det_optimizer.step()
-                    acc += batch_loss_D.detach() / batch_number
-                detector_loss = float(acc)
+                    engine.detector_step(idx, noise_tensor.normal_(), train_encoder=encoder_trainable)
+                mmd_sum, mse_x, mse_p = engine.epoch_sums()
+                # batch_loss_D = -(MMD - .1 mse(batch, batch_dec) - .1 mse(projected, projected_dec)), src/vgan.py:275-277
+                detector_loss = -(mmd_sum - 0.1 * mse_x - 0.1 * mse_p) / batch_number
+                sync_bandwidth()
                 iternum_d += 1
                 iternum_g = 1
             elif iternum_g <= self.iternum_g:
-                acc = torch.zeros((), device=device)
+                # Reference quirk, kept because it decides every number this phase produces: src/vgan.py:308-310 wraps the
+                # generator output in the legacy ``Variable(...)`` constructor, which DETACHES it, and then sets requires_grad
+                # on the detached leaf.  ``batch_loss_G.backward()`` (:326) therefore never reaches the generator's parameters,
+                # ``gen_optimizer.step()`` (:327) sees no gradients and changes nothing: in VGAN.fit the generator keeps its
+                # N(0, 0.1) initialisation (fixture f4: genT == gen0 bit for bit) and this phase only evaluates the loss.
                 for idx in epoch_batches(train_size, self.batch_size):
-                    batch = data[idx.to(device)]
-                    # Reference quirk, kept because it decides every number this phase produces: src/vgan.py:308-310 wraps
-                    # the generator output in the legacy ``Variable(...)`` constructor, which DETACHES it, and then sets
-                    # requires_grad on the detached leaf.  ``batch_loss_G.backward()`` (:326) therefore never reaches the
-                    # generator's parameters, ``gen_optimizer.step()`` (:327) sees no gradients and changes nothing: in
-                    # VGAN.fit the generator keeps its N(0, 0.1) initialisation (fixture f4: genT == gen0 bit for bit) and
-                    # this phase only evaluates the loss.  The backward pass has no observable effect (the gradients it
-                    # leaves on the detector are zeroed before their next use), so it is not run here.
-                    with torch.no_grad():
-                        batch_enc, batch_dec = detector(batch)
-                        fake_subspaces = generator(noise_tensor.normal_().to(device))
-                        projected_enc, projected_dec = detector(fake_subspaces * batch)
-                        batch_loss_G = loss_function(batch_enc, projected_enc, fake_subspaces)
+                    engine.generator_phase_step(idx, noise_tensor.normal_())
                     for p in detector.parameters():  # src/vgan.py:319-320: freezes the detector for good
                         p.requires_grad = False
-                    self.bandwidth = loss_function.bandwidth
-                    acc += batch_loss_G.detach() / batch_number
-                generator_loss = float(acc)
+                    encoder_trainable = False
+                generator_loss = engine.epoch_sums()[0] / batch_number
+                sync_bandwidth()
                 iternum_g += 1
                 if iternum_g > self.iternum_g:
                     iternum_d = 1
