@@ -460,14 +460,20 @@ struct GemmTile {
 // 4-8x more workgroups than with 64x64 tiles, and wave w of a workgroup takes the k-groups [w*BK/32, (w+1)*BK/32) of
 // each BK-deep K tile (BK = 128: 16 MFMAs per wave per K tile, as in the big engine), so the loop is BK/32 = 4x shorter.
 // The four partial accumulators meet in LDS once at the end; wave w then owns result registers 4w..4w+3.
-template <int BK, int LA, int LB, int VEC>
+// NW waves per workgroup (4 or 16): the K loop of these products is bound by the 64-cycle fp32 MFMAs each wave issues
+// back to back (BK = 128, NW = 4: 16 per wave and K tile = 0.43 us), so for long contractions 16 waves (one k-group each)
+// shorten it (measured: M_4 product 10.0 -> 8.9 us, the K = 788 group 10.0 -> 8.2 us; keeping four K tiles of loads in
+// flight on top of that was slower again, 9.9 / 9.6 us); wave w then owns result registers [w*16/NW, (w+1)*16/NW).
+template <int BK, int LA, int LB, int VEC, int NW = 4>
 struct GemmTileKS {
     static constexpr int T = 32;
+    static constexpr int NTH = 64 * NW;
+    static constexpr int NR = 16 / NW;  // result registers per wave
     static constexpr int kImgA = (LA == KC) ? T * (BK + kPad) : BK * (T + kPad);
     static constexpr int kImgB = (LB == KC) ? T * (BK + kPad) : BK * (T + kPad);
     static constexpr int kLdsFloats = 2 * (kImgA + kImgB);
-    static constexpr int GW = BK / 32;  // k-groups (of 8) per wave per K tile
-    static_assert(BK % 32 == 0 && kLdsFloats >= 4 * 16 * 64, "K tile / reduction scratch");
+    static constexpr int GW = BK / (8 * NW);  // k-groups (of 8) per wave per K tile
+    static_assert(GW >= 1 && BK % (8 * NW) == 0 && kLdsFloats >= NW * 16 * 64, "K tile / reduction scratch");
 
     template <int LAYOUT>
     __device__ static __forceinline__ f32x4 frag(const lds_f* img, int mn, int c, int fh) {
@@ -481,7 +487,7 @@ struct GemmTileKS {
 
     // out[rr] (rr = 0..3) = full sum for result register 4*wave + rr of this lane (see row_of / col_of).
     __device__ static __forceinline__ void run(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb, int m0,
-                                               int n0, int M, int N, int K, float* lds_generic, float (&out)[4]) {
+                                               int n0, int M, int N, int K, float* lds_generic, float (&out)[NR]) {
         lds_f* lds = (lds_f*)lds_generic;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int fi = lane & 31, fh = lane >> 5;
@@ -491,8 +497,8 @@ struct GemmTileKS {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const int nk = (K + BK - 1) / BK;
-        Stager<T, BK, LA, VEC> ga;
-        Stager<T, BK, LB, VEC> gb;
+        Stager<T, BK, LA, VEC, false, NTH> ga;
+        Stager<T, BK, LB, VEC, false, NTH> gb;
         ga.init(A, lda, m0, M, K, tid);
         gb.init(B, ldb, n0, N, K, tid);
         ga.load(0);
@@ -543,14 +549,26 @@ struct GemmTileKS {
         for (int r = 0; r < 16; ++r) lds[(wave * 16 + r) * 64 + lane] = acc[r];
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * wave + rr;
-            out[rr] = (lds[(0 * 16 + r) * 64 + lane] + lds[(1 * 16 + r) * 64 + lane]) +
-                      (lds[(2 * 16 + r) * 64 + lane] + lds[(3 * 16 + r) * 64 + lane]);
+        for (int rr = 0; rr < NR; ++rr) {
+            const int r = NR * wave + rr;
+            if constexpr (NW == 4) {
+                out[rr] = (lds[(0 * 16 + r) * 64 + lane] + lds[(1 * 16 + r) * 64 + lane]) +
+                          (lds[(2 * 16 + r) * 64 + lane] + lds[(3 * 16 + r) * 64 + lane]);
+            } else {  // fixed order: quads of waves, then the quads
+                float q[NW / 4];
+#pragma unroll
+                for (int w4 = 0; w4 < NW / 4; ++w4)
+                    q[w4] = (lds[((4 * w4 + 0) * 16 + r) * 64 + lane] + lds[((4 * w4 + 1) * 16 + r) * 64 + lane]) +
+                            (lds[((4 * w4 + 2) * 16 + r) * 64 + lane] + lds[((4 * w4 + 3) * 16 + r) * 64 + lane]);
+                float t = q[0];
+#pragma unroll
+                for (int w4 = 1; w4 < NW / 4; ++w4) t += q[w4];
+                out[rr] = t;
+            }
         }
     }
     __device__ static __forceinline__ int row_of(int rr) {  // row inside the 32x32 tile of out[rr]
-        const int lane = threadIdx.x & 63, r = 4 * (threadIdx.x >> 6) + rr;
+        const int lane = threadIdx.x & 63, r = NR * (threadIdx.x >> 6) + rr;
         return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     }
     __device__ static __forceinline__ int col_of() { return threadIdx.x & 31; }

@@ -33,16 +33,16 @@ __device__ __forceinline__ void tile64(const vgan_gemm_problem& q, int t, float*
     }
 }
 
-template <int LA, int LB, int VEC>
+template <int LA, int LB, int VEC, int NW = 4>
 __device__ __forceinline__ void tile_ks(const vgan_gemm_problem& q, int t, float* lds) {
-    using G = GemmTileKS<QKS, LA, LB, VEC>;
+    using G = GemmTileKS<QKS, LA, LB, VEC, NW>;
     const int gx = (q.n + 31) / 32;
     const int m0 = (t / gx) * 32, n0 = (t % gx) * 32;
-    float o[4];
+    float o[G::NR];
     G::run(q.a, q.lda, q.b, q.ldb, m0, n0, q.m, q.n, q.k, lds, o);
     const int col = n0 + G::col_of();
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < G::NR; ++rr) {
         const int row = m0 + G::row_of(rr);
         if (row < q.m && col < q.n) q.c[(long)row * q.ldc + col] = o[rr];
     }
@@ -72,6 +72,23 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_grouped_kernel(GroupedArgs g) 
     }
 }
 
+// Every problem on 32x32 tiles with 16 waves splitting K (1024-thread workgroups): launches whose products all have a long
+// contraction, where the per-wave MFMA chain is the critical path.
+__global__ __launch_bounds__(1024, 1) void gemm_grouped_ks16_kernel(GroupedArgs g) {
+    constexpr int kLds = cmax(cmax(GemmTileKS<QKS, KC, MC, 4, 16>::kLdsFloats, GemmTileKS<QKS, MC, MC, 4, 16>::kLdsFloats),
+                              GemmTileKS<QKS, KC, KC, 4, 16>::kLdsFloats);
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
+    int qi = 0;
+#pragma unroll
+    for (int i = 1; i < VGAN_GEMM_MAX_GROUP; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.tile_start[i]) qi = i;
+    const vgan_gemm_problem& q = g.p[qi];
+    const int t = blockIdx.x - g.tile_start[qi];
+    if (q.kind == VGAN_GEMM_NN) tile_ks<KC, MC, 4, 16>(q, t, lds);
+    else if (q.kind == VGAN_GEMM_NT) tile_ks<KC, KC, 4, 16>(q, t, lds);
+    else tile_ks<MC, MC, 4, 16>(q, t, lds);
+}
+
 }  // namespace vgan
 
 using namespace vgan;
@@ -99,6 +116,24 @@ extern "C" int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, v
         tiles += g.ks[i] ? ((q.m + 31) / 32) * ((q.n + 31) / 32) : (int)t64;
     }
     for (int i = count; i <= VGAN_GEMM_MAX_GROUP; ++i) g.tile_start[i] = tiles;
+    // all products long-K and few tiles: one 1024-thread launch with every problem on 32x32 tiles
+    int kmin = problems[0].k, t32 = 0;
+    for (int i = 0; i < count; ++i) {
+        kmin = problems[i].k < kmin ? problems[i].k : kmin;
+        t32 += ((problems[i].m + 31) / 32) * ((problems[i].n + 31) / 32);
+    }
+    if (vec && kmin >= 96 && t32 <= 256) {
+        int acc = 0;
+        for (int i = 0; i < count; ++i) {
+            g.ks[i] = 1;
+            g.tile_start[i] = acc;
+            acc += ((problems[i].m + 31) / 32) * ((problems[i].n + 31) / 32);
+        }
+        for (int i = count; i <= VGAN_GEMM_MAX_GROUP; ++i) g.tile_start[i] = acc;
+        hipLaunchKernelGGL(gemm_grouped_ks16_kernel, dim3(acc), dim3(1024), 0, (hipStream_t)stream, g);
+        VGAN_CHECK_LAUNCH();
+        return VGAN_OK;
+    }
     if (vec)
         hipLaunchKernelGGL(gemm_grouped_kernel<4>, dim3(tiles), dim3(kBlock), 0, (hipStream_t)stream, g);
     else

@@ -95,27 +95,28 @@ __global__ __launch_bounds__(kBlock, 2) void linear_bwd_input_ks_kernel(const fl
     using G = GemmTileKS<KSBK, KC, MC, VEC>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    float o[4];
+    float o[G::NR];
     G::run(dy, lddy, W, ldw, m0, n0, n, in, out, lds, o);
     const int col = n0 + G::col_of();
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < G::NR; ++rr) {
         const int row = m0 + G::row_of(rr);
         if (row < n && col < in) dx[(long)row * lddx + col] = o[rr];
     }
 }
-template <int VEC>
-__global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_ks_kernel(const float* __restrict__ dy, int lddy,
-                                                                        const float* __restrict__ x, int ldx, float* __restrict__ dW,
-                                                                        int lddw, int n, int in, int out) {
-    using G = GemmTileKS<KSBK, MC, MC, VEC>;
+template <int VEC, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_bwd_params_ks_kernel(const float* __restrict__ dy, int lddy,
+                                                                                      const float* __restrict__ x, int ldx,
+                                                                                      float* __restrict__ dW, int lddw, int n, int in,
+                                                                                      int out) {
+    using G = GemmTileKS<KSBK, MC, MC, VEC, NW>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    float o[4];
+    float o[G::NR];
     G::run(dy, lddy, x, ldx, m0, n0, out, in, n, lds, o);
     const int col = n0 + G::col_of();
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < G::NR; ++rr) {
         const int row = m0 + G::row_of(rr);
         if (row < out && col < in) dW[(long)row * lddw + col] = o[rr];
     }
@@ -135,11 +136,11 @@ __global__ __launch_bounds__(kBlock, 2) void chain_backward_stage_kernel(const f
     __shared__ __attribute__((aligned(16))) float lds[kLds];
     if ((int)blockIdx.x < nbm) {  // block-uniform
         const int m0 = (blockIdx.x / gx_m) * 32, n0 = (blockIdx.x % gx_m) * 32;
-        float o[4];
+        float o[GK::NR];
         GK::run(Wt, ldwt, Mk, ldm, m0, n0, ek1, e0, ek, lds, o);  // A(i, k) = Wt[k][i], B(j, k) = Mk[k][j]
         const int col = n0 + GK::col_of();
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
+        for (int rr = 0; rr < GK::NR; ++rr) {
             const int row = m0 + GK::row_of(rr);
             if (row < ek1 && col < e0) Mout[(long)row * ldmo + col] = o[rr];
         }
@@ -222,10 +223,12 @@ extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const floa
     const long xs = (long)x_slab_stride;
     if (splits == 1 && x_nslabs == 1 && db == nullptr && use_ks(out, in, n)) {  // tall-skinny: no slabs needed at all
         dim3 g((in + 31) / 32, (out + 31) / 32);
-        if (vec)
-            hipLaunchKernelGGL(linear_bwd_params_ks_kernel<4>, g, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);
+        if (vec && n >= 256)  // long contraction: 16 waves per workgroup (see GemmTileKS)
+            hipLaunchKernelGGL((linear_bwd_params_ks_kernel<4, 16>), g, dim3(1024), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);
+        else if (vec)
+            hipLaunchKernelGGL((linear_bwd_params_ks_kernel<4, 4>), g, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);
         else
-            hipLaunchKernelGGL(linear_bwd_params_ks_kernel<1>, g, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);
+            hipLaunchKernelGGL((linear_bwd_params_ks_kernel<1, 4>), g, dim3(kBlock), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);
         VGAN_CHECK_LAUNCH();
         return VGAN_OK;
     }

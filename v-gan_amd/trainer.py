@@ -323,9 +323,10 @@ class NoKLStepEngine:
         # M_{k-1} = Wt_k^T M_k, i.e. M_3 = Wt_4^T M_4, M_2 = B_3^T M_4, M_1 = B_2^T M_4 (At_0 = I: Gt_1 IS M_1), and
         # [dW_k | db_k] = Gt_k = M_k . At_{k-1}^T: two dependency levels
         M, Gt, At = self.M, self.Gt, self.At
-        ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1]),
-                          ("NT", M[4], At[3], Gt[4])])
-        ops.gemm_grouped([("NT", M[3], At[2], Gt[3]), ("NT", M[2], At[1], Gt[2])])
+        # (launches are kept homogeneous -- long contractions in one, short ones in the other -- so that the library can run
+        # the long-K group on its 16-wave tiles)
+        ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])])
+        ops.gemm_grouped([("NT", M[4], At[3], Gt[4]), ("NT", M[3], At[2], Gt[3]), ("NT", M[2], At[1], Gt[2])])
         fused_noise = dict(next_noise=self.za, noise_cols=self.L, noise_ones_col=self.L, seed=self.seed,
                            step_counter=self.step_counter) if self.noise_mode == "device" else {}
         ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
