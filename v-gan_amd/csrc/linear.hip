@@ -15,11 +15,11 @@ __global__ __launch_bounds__(kBlock, 2) void linear_fwd_kernel(const float* __re
     using G = GemmTile<LBM, LBN, LBK, KC, KC, VEC, XSL ? 1 : 0>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    const int col = n0 + G::sub_col(0);
+    const float bias = (b != nullptr) ? b[min(col, out - 1)] : 0.f;  // requested before the main loop, not after it
     f32x16 acc[G::WM][G::WN];
     zero_acc(acc);
     G::template run<false>(x, ldx, W, ldw, m0, n0, n, out, in, lds, nullptr, acc, x_nslabs, x_slab_stride);
-    const int col = n0 + G::sub_col(0);
-    const float bias = (b != nullptr && col < out) ? b[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + G::sub_row(0, r);

@@ -97,16 +97,21 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_gram_bf3_kernel(
         return;
     }
     const TileDesc td = tiles[blockIdx.x];
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    G::template run<false>(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, nullptr, acc);
-
+    // the epilogue's operands (row norms, bandwidth) are requested BEFORE the main loop: issued after it they would add one
+    // full memory latency (~1 us) to every tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = td.c0 + G::sub_col();
     const bool jok = j < td.clim;
     const float sj = sq[min(j, td.clim - 1)];
     const float bw = bw_ptr[0];
+    float si_pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) si_pre[r] = sq[min(td.r0 + G::sub_row(r), td.rlim - 1)];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    G::template run<false>(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, nullptr, acc);
+
     const float c2 = -1.4426950408889634f / (4.f * bw);
     const float wscale = -((td.flags & VGAN_TF_NEG) ? -1.f : 1.f) * 2.f / ((float)n * (float)n * bw);
     const bool store = (td.flags & VGAN_TF_STORE) && Wh != nullptr;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_gram_bf3_kernel(
     for (int r = 0; r < 16; ++r) {
         const int lrow = G::sub_row(r), i = td.r0 + lrow;
         const bool ok = jok && (i < td.rlim);
-        const float si = sq[min(i, td.rlim - 1)];
+        const float si = si_pre[r];
         const float L = fmaxf(si + sj - 2.f * acc[r], 0.f);
         const float t = __builtin_amdgcn_exp2f(L * c2);
         const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
@@ -199,6 +204,18 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
         return;
     }
     const TileDesc td = tiles[blockIdx.x];
+    // epilogue operands requested before the main loop (see mmd_gram_bf3_kernel)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lcol = G::sub_col();
+    const int j = td.c0 + lcol;
+    const bool jok = j < td.clim;
+    const float sj = sq[min(j, td.clim - 1)];
+    const float bw = bw_ptr[0];
+    float si_pre[2][16];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) si_pre[i2][r] = sq[min(td.r0 + G::sub_row(i2, r), td.rlim - 1)];
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -206,12 +223,6 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     G::run(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, acc);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lcol = G::sub_col();
-    const int j = td.c0 + lcol;
-    const bool jok = j < td.clim;
-    const float sj = sq[min(j, td.clim - 1)];
-    const float bw = bw_ptr[0];
     const float c2 = -1.4426950408889634f / (4.f * bw);
     const float wscale = -((td.flags & VGAN_TF_NEG) ? -1.f : 1.f) * 2.f / ((float)n * (float)n * bw);
     const bool store = (td.flags & VGAN_TF_STORE) && Wh != nullptr;
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
         for (int r = 0; r < 16; ++r) {
             const int lrow = G::sub_row(i2, r), i = td.r0 + lrow;
             const bool ok = jok && (i < td.rlim);
-            const float si = sq[min(i, td.rlim - 1)];
+            const float si = si_pre[i2][r];
             const float L = fmaxf(si + sj - 2.f * acc[i2][r], 0.f);
             const float t = __builtin_amdgcn_exp2f(L * c2);
             const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
@@ -322,16 +333,24 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
     // split-K slice blockIdx.y of the row-of-W range (whole K tiles); slab = its share of rowsum and of the product
     const int k0 = blockIdx.y * kchunk, klen = min(kchunk, kn - k0);
     out += blockIdx.y * slab_stride;
+    // the epilogue's operands (z and the multiplier, clamped addresses) are requested BEFORE the main loop: issued after it
+    // they would add one full memory latency to every tile
+    const int col = n0 + G::sub_col(), colc = min(col, p - 1);
+    float z_pre[16], m_pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rowc = min(m0 + G::sub_row(r), nr - 1);
+        z_pre[r] = Z[(long)(wrow0 + rowc) * ldz + colc];
+        m_pre[r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] : 1.f;
+    }
     if (klen > 0) G::template run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, gx * 64, klen, lds, rs, acc);
-    const int col = n0 + G::sub_col();
     if (col >= p) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int lrow = G::sub_row(r), row = m0 + lrow;
         if (row < nr) {
-            float v = klen > 0 ? 2.f * (rs[lrow] * Z[(long)(wrow0 + row) * ldz + col] - acc[r]) : 0.f;
-            if (mul != nullptr) v *= mul[(long)row * ldmul + col];
-            out[(long)row * ldo + col] = v;
+            const float v = klen > 0 ? 2.f * (rs[lrow] * z_pre[r] - acc[r]) : 0.f;
+            out[(long)row * ldo + col] = v * m_pre[r];
         }
     }
 }
