@@ -94,11 +94,11 @@ __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5
 
 __device__ __forceinline__ void noise_normal_body(float* __restrict__ z, int rows, int cols, int ld, int ones_col,
                                                   unsigned long long seed, const unsigned long long* __restrict__ step_counter,
-                                                  unsigned long long stream_id) {
+                                                  unsigned long long stream_id, int vblock, int vgrid) {
     const unsigned long long step = step_counter ? step_counter[0] : 0ull;
     const long count = (long)rows * cols;
     const long nq = (count + 3) >> 2;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    for (long q = (long)vblock * blockDim.x + threadIdx.x; q < nq; q += (long)vgrid * blockDim.x) {
         unsigned c[4] = {(unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)step, (unsigned)(step >> 32)};
         philox4x32_10(c, (unsigned)seed ^ (unsigned)stream_id, (unsigned)(seed >> 32) ^ (unsigned)(stream_id >> 32) ^ 0x5bd1e995u);
         float o[4];
@@ -117,13 +117,13 @@ __device__ __forceinline__ void noise_normal_body(float* __restrict__ z, int row
         }
     }
     if (ones_col >= 0)  // homogeneous coordinate [z | 1] of the collapsed generator chain
-        for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) z[r * ld + ones_col] = 1.0f;
+        for (long r = (long)vblock * blockDim.x + threadIdx.x; r < rows; r += (long)vgrid * blockDim.x) z[r * ld + ones_col] = 1.0f;
 }
 
 __global__ __launch_bounds__(kBlock) void noise_normal_kernel(float* __restrict__ z, int rows, int cols, int ld, int ones_col,
                                                              unsigned long long seed, const unsigned long long* __restrict__ step_counter,
                                                              unsigned long long stream_id) {
-    noise_normal_body(z, rows, cols, ld, ones_col, seed, step_counter, stream_id);
+    noise_normal_body(z, rows, cols, ld, ones_col, seed, step_counter, stream_id, blockIdx.x, gridDim.x);
 }
 
 // Adadelta for the collapsed generator chain: the gradient of flat element i is read from the packed (homogeneous)
@@ -134,21 +134,30 @@ __global__ __launch_bounds__(kBlock) void adadelta_packed_kernel(float* __restri
                                                                 float* __restrict__ sq, float* __restrict__ acc, long count, float lr,
                                                                 float rho, float eps, float wd, float gs, float* __restrict__ z,
                                                                 int zrows, int zcols, int zld, int zones, unsigned long long seed,
-                                                                const unsigned long long* __restrict__ step_counter) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += stride) {
-        const int m = pmap[q];
-        if (m < 0) continue;
-        float pv = p[q], v = sq[q], a = acc[q];
-        adadelta_one(pv, gpacked[m], v, a, lr, rho, eps, wd, gs);
-        p[q] = pv;
-        sq[q] = v;
-        acc[q] = a;
-        wpacked[m] = pv;
+                                                                const unsigned long long* __restrict__ step_counter, int elem_blocks,
+                                                                int noise_blocks) {
+    const int b = blockIdx.x;
+    if (b < elem_blocks) {
+        // every load of an element is issued at once (the state reads do not wait for the index map); only the packed
+        // gradient needs the map -- two dependent accesses instead of three
+        const long stride = (long)elem_blocks * blockDim.x;
+        for (long q = (long)b * blockDim.x + threadIdx.x; q < count; q += stride) {
+            const int m = pmap[q];
+            float pv = p[q], v = sq[q], a = acc[q];
+            if (m < 0) continue;
+            adadelta_one(pv, gpacked[m], v, a, lr, rho, eps, wd, gs);
+            p[q] = pv;
+            sq[q] = v;
+            acc[q] = a;
+            wpacked[m] = pv;
+        }
+    } else {
+        // The optimiser is the last kernel of a step and the noise draw the first of the next one: the draw for the NEXT
+        // step (the step counter was already advanced by the loss kernel) rides along here, in workgroups of its own.
+        // (Also gathering the next step's batch rows here was measured: this launch 5.1 -> 8.6 us for 0.2 us off the
+        // mask/projection kernel -- the gather's cold HBM rows are what costs, wherever it runs.)
+        noise_normal_body(z, zrows, zcols, zld, zones, seed, step_counter, 0ull, b - elem_blocks, noise_blocks);
     }
-    // The optimiser is the last kernel of a step and the noise draw the first of the next one: the draw for the NEXT
-    // step (the step counter was already advanced by the loss kernel) rides along here instead of costing a launch.
-    if (z != nullptr) noise_normal_body(z, zrows, zcols, zld, zones, seed, step_counter, 0ull);
 }
 
 // Homogeneous packing of Linear layers: Wt = [[W, b], [0, 1]] (zero padded to multiples of 4), so that a chain of
@@ -259,9 +268,12 @@ extern "C" int vgan_adadelta_step_packed(float* p, const int32_t* pmap, const fl
                                          int noise_ones_col, uint64_t seed, const uint64_t* step_counter, vgan_stream_t stream) {
     VGAN_CHECK_ARG(p && pmap && g_packed && w_packed && sq_avg && acc_delta && count > 0);
     VGAN_CHECK_ARG(next_noise == nullptr || (noise_rows > 0 && noise_cols > 0 && noise_ld >= noise_cols && noise_ones_col < noise_ld));
-    hipLaunchKernelGGL(adadelta_packed_kernel, dim3(stream_grid(count)), dim3(kBlock), 0, (hipStream_t)stream, p, pmap, g_packed, w_packed,
-                       sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale, next_noise, noise_rows, noise_cols,
-                       noise_ld, noise_ones_col, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step_counter));
+    const int elem_blocks = stream_grid(count);
+    const int noise_blocks = next_noise != nullptr ? stream_grid(((long)noise_rows * noise_cols + 3) / 4) : 0;
+    hipLaunchKernelGGL(adadelta_packed_kernel, dim3(elem_blocks + noise_blocks), dim3(kBlock), 0, (hipStream_t)stream, p,
+                       pmap, g_packed, w_packed, sq_avg, acc_delta, (long)count, lr, rho, eps, weight_decay, grad_scale, next_noise,
+                       noise_rows, noise_cols, noise_ld, noise_ones_col, (unsigned long long)seed,
+                       reinterpret_cast<const unsigned long long*>(step_counter), elem_blocks, noise_blocks);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
