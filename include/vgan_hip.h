@@ -239,6 +239,14 @@ typedef struct vgan_gemm_problem {
 } vgan_gemm_problem;
 int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_t stream);
 
+/* vgan_mask_project_forward fused with vgan_mmd_bf3_prepare for the training step: from logits [n, d] and the
+ * batch rows it writes S [n, d], Z = [X ; U*X] ([2n, ldz] fp32), sq [2n] and the split images Zh, Zl [2n, kp],
+ * ZTh, ZTl [kp, kn] of Z (pad regions are not touched: pre-zeroed by the caller).  Shape contract: d % 4 == 0,
+ * d <= 1024, n % 8 == 0, leading dimensions % 4 == 0, 16-byte aligned bases; otherwise use the two calls. */
+int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
+                                  const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z,
+                                  int ldz, float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,
+                                  uint16_t* ZTl, int kn, int n, int d, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

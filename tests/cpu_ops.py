@@ -97,6 +97,15 @@ class CpuOps:
             sqx.copy_(torch.as_tensor((X.astype(np.float64) ** 2).sum(1)))
         sqy.copy_(torch.as_tensor((Y.astype(np.float64) ** 2).sum(1)))
 
+    def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0):
+        n, d = logits.shape
+        self.mask_project_forward(logits, data, rows, S, None, Z[:n], Z[n:], sq[:n], sq[n:], row_cursor, row_batches, row_stride)
+        self.mmd_bf3_prepare(Z, 2 * n, d, Zh, Zl, ZTh, ZTl)
+
+    @staticmethod
+    def bf3_fusable(n, d, *lds):
+        return d % 4 == 0 and d <= 1024 and n % 8 == 0 and all(int(v) % 4 == 0 for v in lds)
+
     def gather_rows(self, data, rows, out, sq, row_cursor=None, row_batches=1, row_stride=0, row_offset=0):
         n, d = out.shape[0], data.shape[1]
         X = _np(data)[self._rows(rows, row_cursor, row_batches, row_stride, row_offset, n)]

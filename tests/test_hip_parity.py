@@ -856,3 +856,33 @@ def test_kl_step_engine_hip_vs_cpu_provider(ops, n, d):
     np.testing.assert_allclose(res["hip"][1], res["cpu"][1], rtol=1e-5)
     for a, b in zip(res["hip"][2], res["cpu"][2]):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,d", [(1024, 784), (264, 1024), (72, 20), (128, 100)])
+def test_mask_project_forward_bf3_equals_two_launches(ops, n, d):
+    """vgan_mask_project_forward_bf3 (mask/projection fused with the bf16x3 operand preparation) is bit-identical to
+    vgan_mask_project_forward followed by vgan_mmd_bf3_prepare: S, Z, row norms, and all four split images."""
+    rng = np.random.default_rng(n * 7 + d)
+    rows_total = 3 * n
+    data = dev(rng.normal(size=(rows_total, d)).astype(np.float32))
+    logits = dev((rng.normal(size=(n, d)) * 2.0).astype(np.float32))
+    perm = torch.as_tensor(np.stack([rng.permutation(rows_total)[:n] for _ in range(2)]).astype(np.int32)).cuda()
+    cursor = torch.full((1,), 3, dtype=torch.int64, device="cuda")  # 3 % 2 -> second index row
+    dp, kp, kn = (d + 3) // 4 * 4, (d + 63) // 64 * 64, (2 * n + 63) // 64 * 64
+    i16 = dict(dtype=torch.int16, device="cuda")
+
+    def buffers():
+        return dict(S=torch.zeros(n, d, device="cuda"), Z=torch.zeros(2 * n, dp, device="cuda"), sq=torch.zeros(2 * n, device="cuda"),
+                    Zh=torch.zeros(2 * n, kp, **i16), Zl=torch.zeros(2 * n, kp, **i16), ZTh=torch.zeros(kp, kn, **i16),
+                    ZTl=torch.zeros(kp, kn, **i16))
+
+    a, b = buffers(), buffers()
+    sel = dict(row_cursor=cursor, row_batches=2, row_stride=n)
+    ops.mask_project_forward(logits, data, perm, a["S"], None, a["Z"][:n], a["Z"][n:], a["sq"][:n], a["sq"][n:], **sel)
+    ops.mmd_bf3_prepare(a["Z"], 2 * n, d, a["Zh"], a["Zl"], a["ZTh"], a["ZTl"])
+    assert ops.bf3_fusable(n, d, logits.stride(0), data.stride(0), dp)
+    ops.mask_project_forward_bf3(logits, data, perm, b["S"], b["Z"], b["sq"], b["Zh"], b["Zl"], b["ZTh"], b["ZTl"], **sel)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["Z"][:n, :d].abs().sum()) > 0 and int((a["ZTh"] != 0).sum()) > 0

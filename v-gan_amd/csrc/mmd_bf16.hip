@@ -17,12 +17,6 @@
 
 namespace vgan {
 
-__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
-__device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned short& lo) {
-    hi = bf16_bits(v);
-    lo = bf16_bits(v - bf16_val(hi));
-}
 
 // ---- operand preparation: 64x64 tiles of Z -> row-major and transposed hi/lo images ---------------------------
 // Zh/Zl [rows_pad, kp]  (kp = features padded to 64, zero filled);  ZTh/ZTl [kp, kn]  (kn = rows padded to 64)

@@ -133,6 +133,118 @@ __global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* _
     }
 }
 
+// ---- the same forward fused with the operand preparation of the bf16x3 MMD kernels (vgan_mmd_bf3_prepare) -----------
+// A workgroup owns 8 consecutive batch rows (two per wave) and emits, besides everything mask_forward_vec_kernel emits,
+// the split images of both the X row and the Y = U*X row: row-major (Zh, Zl) straight from registers, transposed
+// (ZTh, ZTl: [feature][row]) through an LDS tile, so that 8 rows leave as one 16-byte store per feature and image.  This
+// removes the separate preparation launch (~6 us of a ~120 us step at d = 784) and its 13 MB re-read of Z.
+template <int NT>
+__global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
+                                                                 int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ Z,
+                                                                 int ldz, float* __restrict__ sq, unsigned short* __restrict__ Zh,
+                                                                 unsigned short* __restrict__ Zl, int kp, unsigned short* __restrict__ ZTh,
+                                                                 unsigned short* __restrict__ ZTl, int kn, int n, int d) {
+    constexpr int R = 8;                                  // rows per workgroup = waves per workgroup (512 threads)
+    extern __shared__ __attribute__((aligned(16))) unsigned short tile[];  // [4 images: Xh, Xl, Yh, Yl][R][ldt]
+    const int ldt = 4 * (d >> 2) + 8;                     // bf16 elements per tile row (8-byte stores stay aligned)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = d >> 2;
+    // Workgroup -> row group: block b runs on XCD b % 8 (private L2 each).  The eight row groups that share the 128-byte
+    // lines of the transposed images (8 rows = 16 bytes each) must meet in ONE L2, or every line is written back partially
+    // by up to eight of them: XCD x takes the contiguous range of groups [x C, (x + 1) C).
+    const int groups = n / R, C = (groups + 7) / 8;
+    const int grp = (blockIdx.x % 8) * C + blockIdx.x / 8;
+    if (grp >= groups) return;
+    const int i0 = grp * R;
+    const float tau = 1.0f / (float)d;
+    {
+        const int lr = wave, i = i0 + lr;
+        if (i < n) {
+            const float4* x4 = reinterpret_cast<const float4*>(logits + (long)i * ldl);
+            const float4* xr4 = reinterpret_cast<const float4*>(data + rows(i) * ldd);
+            float4 v[NT], xv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int q = lane + 64 * t;
+                const bool ok = q < nq;
+                v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                xv[t] = xr4[min(q, nq - 1)];
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) m = fmaxf(m, fmaxf(fmaxf(v[t].x, v[t].y), fmaxf(v[t].z, v[t].w)));
+            m = wave_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                v[t].x = expf(v[t].x - m); v[t].y = expf(v[t].y - m); v[t].z = expf(v[t].z - m); v[t].w = expf(v[t].w - m);
+                sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+            }
+            sum = wave_sum(sum);
+            float nx = 0.f, ny = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int q = lane + 64 * t;
+                if (q < nq) {
+                    const float4 s4 = make_float4(v[t].x / sum, v[t].y / sum, v[t].z / sum, v[t].w / sum);
+                    const float4 u4 = make_float4(s4.x < tau ? s4.x : 1.f, s4.y < tau ? s4.y : 1.f, s4.z < tau ? s4.z : 1.f, s4.w < tau ? s4.w : 1.f);
+                    const float4 y4 = make_float4(u4.x * xv[t].x, u4.y * xv[t].y, u4.z * xv[t].z, u4.w * xv[t].w);
+                    reinterpret_cast<float4*>(S + (long)i * d)[q] = s4;
+                    reinterpret_cast<float4*>(Z + (long)i * ldz)[q] = xv[t];
+                    reinterpret_cast<float4*>(Z + (long)(n + i) * ldz)[q] = y4;
+                    nx += (xv[t].x * xv[t].x + xv[t].y * xv[t].y) + (xv[t].z * xv[t].z + xv[t].w * xv[t].w);
+                    ny += (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
+                    const float xs[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+                    unsigned short h[2][4], l[2][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        split_bf16(xs[e], h[0][e], l[0][e]);
+                        split_bf16(ys[e], h[1][e], l[1][e]);
+                    }
+#pragma unroll
+                    for (int im = 0; im < 2; ++im) {  // 0: X row i, 1: Y row n + i
+                        const uint2 ph = make_uint2((unsigned)h[im][0] | ((unsigned)h[im][1] << 16), (unsigned)h[im][2] | ((unsigned)h[im][3] << 16));
+                        const uint2 pl = make_uint2((unsigned)l[im][0] | ((unsigned)l[im][1] << 16), (unsigned)l[im][2] | ((unsigned)l[im][3] << 16));
+                        const long grow = (long)(im * n + i) * kp + 4 * q;
+                        *reinterpret_cast<uint2*>(Zh + grow) = ph;
+                        *reinterpret_cast<uint2*>(Zl + grow) = pl;
+                        *reinterpret_cast<uint2*>(tile + ((2 * im) * R + lr) * ldt + 4 * q) = ph;
+                        *reinterpret_cast<uint2*>(tile + ((2 * im + 1) * R + lr) * ldt + 4 * q) = pl;
+                    }
+                }
+            }
+            nx = wave_sum(nx);
+            ny = wave_sum(ny);
+            if (lane == 0) {
+                sq[i] = nx;
+                sq[n + i] = ny;
+            }
+        } else {  // rows past the batch: their tile rows are read by the transposed store below (full 16-byte pieces)
+            for (int c = lane; c < ldt; c += 64)
+#pragma unroll
+                for (int im = 0; im < 4; ++im) tile[(im * R + lr) * ldt + c] = 0;
+        }
+    }
+    __syncthreads();
+    // transposed images: features (j, j+1), rows i0 .. i0+7 of image X (columns i0..) and Y (columns n + i0 ..): per image
+    // eight 4-byte LDS reads (two features at once) and one 16-byte store per feature
+    const int npairs = d >> 1;
+    for (int item = threadIdx.x; item < 4 * npairs; item += 512) {
+        const int im = item / npairs, j = 2 * (item - im * npairs);
+        unsigned w0[4], w1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned a = *reinterpret_cast<const unsigned*>(tile + (im * R + 2 * e) * ldt + j);
+            const unsigned c = *reinterpret_cast<const unsigned*>(tile + (im * R + 2 * e + 1) * ldt + j);
+            w0[e] = (a & 0xFFFFu) | (c << 16);
+            w1[e] = (a >> 16) | (c & 0xFFFF0000u);
+        }
+        unsigned short* dst = ((im & 1) ? ZTl : ZTh) + (long)j * kn + (im >> 1) * n + i0;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+        *reinterpret_cast<uint4*>(dst + kn) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(kBlock) void mask_backward_vec_kernel(const float* __restrict__ gU, int ldg, const float* __restrict__ S,
                                                                   int lds, const unsigned long long* __restrict__ colkey,
@@ -275,6 +387,36 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
 #undef VGAN_LAUNCH_FWD
     } else
         hipLaunchKernelGGL(mask_forward_kernel<true>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
+                                             const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z, int ldz,
+                                             float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh, uint16_t* ZTl, int kn,
+                                             int n, int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(logits && data && S && Z && sq && Zh && Zl && ZTh && ZTl && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
+    VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && kp >= d && kp % 64 == 0 && kn >= 2 * n && kn % 64 == 0);
+    // shape contract of the fused path (callers fall back to vgan_mask_project_forward + vgan_mmd_bf3_prepare otherwise)
+    VGAN_CHECK_ARG(d % 4 == 0 && d <= 1024 && n % 8 == 0 && ldl % 4 == 0 && ldd % 4 == 0 && ldz % 4 == 0);
+    VGAN_CHECK_ARG(aligned16(logits) && aligned16(data) && aligned16(S) && aligned16(Z) && aligned16(Zh) && aligned16(Zl) &&
+                   aligned16(ZTh) && aligned16(ZTl));
+    const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, 0};
+    const dim3 grid(8 * ((n / 8 + 7) / 8)), block(512);
+    const size_t shmem = (size_t)4 * 8 * (d + 8) * sizeof(unsigned short);
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = (d / 4 + 63) / 64;
+    // (dynamic LDS above 64 KB -- d close to 1024 -- needs the opt-in; setting it is idempotent and cheap)
+#define VGAN_LAUNCH_FWD3(NT)                                                                                                        \
+    do {                                                                                                                            \
+        if (shmem > 64 * 1024)                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_bf3_kernel<NT>),                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                      \
+        hipLaunchKernelGGL(mask_forward_bf3_kernel<NT>, grid, block, shmem, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, Zh, Zl, kp, \
+                           ZTh, ZTl, kn, n, d);                                                                                     \
+    } while (0)
+    if (nt == 1) VGAN_LAUNCH_FWD3(1); else if (nt == 2) VGAN_LAUNCH_FWD3(2); else if (nt == 3) VGAN_LAUNCH_FWD3(3); else VGAN_LAUNCH_FWD3(4);
+#undef VGAN_LAUNCH_FWD3
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -99,6 +99,14 @@ __device__ __forceinline__ void colmax_partial_body(const float* __restrict__ S,
     }
 }
 
+// z = hi + lo with hi = bf16(z) (round to nearest even), lo = bf16(z - hi): the operand split of the bf16x3 MMD kernels
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned short& lo) {
+    hi = bf16_bits(v);
+    lo = bf16_bits(v - bf16_val(hi));
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace vgan

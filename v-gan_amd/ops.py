@@ -101,6 +101,19 @@ class HipOps:
                                                       _ptr(row_cursor), int(row_batches), int(row_stride), int(row_offset), _ptr(S), _ptr(U), _ptr(Zx), _ptr(Zy), Zy.stride(0), _ptr(sqx), _ptr(sqy),
                                                       n, d, self._stream()), "vgan_mask_project_forward")
 
+    def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0):
+        """mask_project_forward + mmd_bf3_prepare in one launch (shape contract in include/vgan_hip.h; see bf3_fusable)."""
+        _mat(logits, "logits"), _mat(data, "data"), _mat(Z, "Z")
+        n, d = logits.shape
+        _lib.check(self.lib.vgan_mask_project_forward_bf3(_ptr(logits), logits.stride(0), _ptr(data), data.stride(0), _ptr(rows),
+                                                          _ptr(row_cursor), int(row_batches), int(row_stride), _ptr(S), _ptr(Z), Z.stride(0),
+                                                          _ptr(sq), _ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(ZTh), _ptr(ZTl), ZTh.stride(0),
+                                                          n, d, self._stream()), "vgan_mask_project_forward_bf3")
+
+    @staticmethod
+    def bf3_fusable(n, d, *lds):
+        return d % 4 == 0 and d <= 1024 and n % 8 == 0 and all(int(v) % 4 == 0 for v in lds)
+
     def gather_rows(self, data, rows, out, sq, row_cursor=None, row_batches=1, row_stride=0, row_offset=0):
         _mat(data, "data"), _mat(out, "out")
         n, d = out.shape[0], data.shape[1]

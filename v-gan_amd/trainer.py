@@ -203,6 +203,8 @@ class NoKLStepEngine:
             self.Zh, self.Zl = torch.zeros(2 * n, self.kp, **i16), torch.zeros(2 * n, self.kp, **i16)
             self.ZTh, self.ZTl = torch.zeros(self.kp, self.kn, **i16), torch.zeros(self.kp, self.kn, **i16)
             self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
+        self.fused_prepare = (self.bf3 and ops.bf3_fusable(n, d, self.logits.stride(0), data.stride(0), dp) and
+                              os.environ.get("VGAN_FUSED_PREPARE", "1") == "1")
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         # Gram tile edge: the split-bf16 Gram has a 128x128 variant (half the L2 -> LDS bytes per flop, one 512-thread
         # workgroup per CU).  Measured: c5 330 vs 273 TFLOP/s algorithmic, c3 (136 tiles of 128) no gain (26.3 vs 25.6 us),
@@ -343,6 +345,10 @@ class NoKLStepEngine:
             ops.noise_normal(self.za, self.seed, self.step_counter, 0, cols=self.L, ones_col=self.L)
         self._generator_forward()
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
+        if self.fused_prepare:  # mask/projection and the bf16x3 operand split in one launch
+            ops.mask_project_forward_bf3(self.logits, self.data, self.perm, self.S, self.Z, self.sqn, self.Zh, self.Zl, self.ZTh, self.ZTl,
+                                         **rowsel)
+            return
         ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n], self.sqn[n:],
                                  row_offset=0, **rowsel)
 
@@ -359,7 +365,7 @@ class NoKLStepEngine:
         dist = self._collect() if self.exchange else None
         gstride = nl * self.dp
         bf3 = self.precision == "bf16x3"
-        if bf3:
+        if bf3 and not self.fused_prepare:
             ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
         if bf3:
             ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
