@@ -1,3 +1,9 @@
+#!/bin/bash
+# One round of evidence on a GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh'
+# GPU test tier, the default bench line, the rocprofv3 kernel statistics of a bench run, and the separate PMC passes that
+# tools/pmc_traffic.py folds into profiles/traffic.json.  Everything lands under gpurun_out/; copy what is to be kept into
+# profiles/.  (rocprofv3 gets the program itself after `--`, never a wrapper: see the pool rules.)
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $R/gpurun_out/pytest16.log 2>&1; rc=$?; tail -3 $R/gpurun_out/pytest16.log; [ $rc -eq 0 ] || exit 1
