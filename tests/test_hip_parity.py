@@ -416,11 +416,12 @@ def test_vgan_kernel_learning_fit_matches_reference_run():
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
 
 
-@pytest.mark.parametrize("n,d,rows", [(500, 166, 1500), (96, 33, 300), (250, 784, 500), (600, 901, 1250)])
+@pytest.mark.parametrize("n,d,rows", [(500, 166, 1500), (96, 33, 300), (250, 784, 500), (600, 901, 1250), (600, 900, 1250)])
 def test_ragged_shapes_trajectory_vs_oracle(ops, n, d, rows):
     """Default-like batch sizes that are no multiple of the 64-wide tile (the reference's default is 500), feature counts
     that are no multiple of 4, and an epoch with a dropped remainder: 6 steps against the fp64 oracle.  The precision
-    mode is the engine's own choice ("auto"): fp32 kernels for the first three shapes, split-bf16 for the last."""
+    mode is the engine's own choice ("auto"): fp32 kernels for the first three shapes, split-bf16 for the last two -- with
+    the two-launch forward (d = 901) and with the fused forward on a batch that is no multiple of the 64-row tile (d = 900)."""
     rng = np.random.default_rng(n + d)
     data = (rng.normal(size=(rows, d)) * rng.uniform(0.5, 2.0, size=(1, d))).astype(np.float32)
     params = orc.synthetic_generator_params(d, seed=3)
@@ -428,6 +429,7 @@ def test_ragged_shapes_trajectory_vs_oracle(ops, n, d, rows):
     nb = rows // n
     eng, _ = make_engine(ops, params, data, n, nb=nb, graph=True)
     assert eng.precision == ("bf16x3" if 2 * n * d >= (1 << 20) else "fp32")
+    assert eng.fused_prepare == (eng.precision == "bf16x3" and d % 4 == 0)
     ref = orc.NoKLTrainer([p.astype(np.float64) for p in params])
     perm = np.stack([rng.permutation(rows)[:n] for _ in range(nb)])
     eng.set_epoch_batches(torch.as_tensor(perm))
