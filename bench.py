@@ -109,7 +109,10 @@ def kernel_rooflines(eng):
         out[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "flop": flop}
 
     Wg = eng.Wg if not eng.bf3 else torch.zeros(nl, 2 * n, device=eng.Z.device)
-    add("mmd_gram_kernel<4,false,1>", time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, eng.tiles, False, Wg, n + lo, eng.partial)))
+    # the fp32 kernels work on 64-wide tiles: their own table when the engine runs the 128-wide bf16x3 Gram
+    tiles64 = eng.tiles if eng.gram_tile == 64 else ops.build_tiles(n, 1, eng.rank, eng.world, device=eng.Z.device)
+    part64 = torch.zeros(tiles64.shape[0], 4, device=eng.Z.device)
+    add("mmd_gram_kernel<4,false,1>", time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, tiles64, False, Wg, n + lo, part64)))
     add("mmd_backward_kernel<4,2>", time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU)))
     if eng.bf3:
         gs = nl * eng.dp
