@@ -228,23 +228,37 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    # rehearsal knobs (a one-GPU box cannot run RCCL between two ranks of the same device): VGAN_BENCH_BACKEND=gloo puts all
+    # ranks on device VGAN_BENCH_DEVICE and carries the collectives through the host (no graph capture then)
+    backend = os.environ.get("VGAN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = int(os.environ.get("VGAN_BENCH_DEVICE", "0"))
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(1234)
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and backend == "nccl"
     ekw = {"mmd_precision": args.precision} if args.precision else {}
     eng, data, params = build_engine(rank, world, use_graph, **ekw)
     def prewarm(e):
-        t_end, k = time.perf_counter() + args.prewarm_seconds, 0
-        while time.perf_counter() < t_end:
-            run_steps(e, EPOCH_BATCHES, k)
-            k += EPOCH_BATCHES
-            torch.cuda.synchronize()
+        # every rank must run the SAME number of steps (each one holds a collective and draws the shared shuffles): rank 0
+        # times one epoch and broadcasts how many more to run
+        t0 = time.perf_counter()
+        run_steps(e, EPOCH_BATCHES, 0)
+        torch.cuda.synchronize()
+        more = torch.tensor([max(0, min(2000, int(args.prewarm_seconds / max(time.perf_counter() - t0, 1e-6))))], device="cuda")
+        if dist:
+            dist.broadcast(more, src=0)
+        for it in range(int(more.item())):
+            run_steps(e, EPOCH_BATCHES, (it + 1) * EPOCH_BATCHES)
+        torch.cuda.synchronize()
 
     try:
         prewarm(eng)
