@@ -297,12 +297,26 @@ struct GemmBF3Big {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) *(lds_u4*)(buf + part * PART + lofs[r]) = v[part][r];
         }
+        // sum over k of the staged A values (hi + lo) of staged piece r
+        __device__ __forceinline__ float a_rowpart(int r) const {
+            float s = 0.f;
+            const unsigned* h = reinterpret_cast<const unsigned*>(&v[0][r]);
+            const unsigned* l = reinterpret_cast<const unsigned*>(&v[1][r]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s += __uint_as_float(h[e] << 16) + __uint_as_float(h[e] & 0xFFFF0000u);
+                s += __uint_as_float(l[e] << 16) + __uint_as_float(l[e] & 0xFFFF0000u);
+            }
+            return s;
+        }
     };
 
-    // acc[i] (+)= A[m0 + 64 wr + 32 i .., :] . B[n0 + 32 wc .., :]^T over K (a multiple of 64)
+    // acc[i] (+)= A[m0 + 64 wr + 32 i .., :] . B[n0 + 32 wc .., :]^T over K (a multiple of 64).
+    // SIDE_A: rs_generic[128] = sum_k A[m0 + m, k] (the row sums the backward product needs).
+    template <bool SIDE_A = false>
     __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
                                                const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K,
-                                               char* lds_generic, f32x16 (&acc)[2]) {
+                                               char* lds_generic, f32x16 (&acc)[2], float* rs_generic = nullptr) {
         typedef char __attribute__((address_space(3))) lds_c;
         lds_c* lds = (lds_c*)lds_generic;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,8 +325,14 @@ struct GemmBF3Big {
         Stage st;
         st.init(Ah, Al, lda, m0, M, Bh, Bl, ldb, n0, N, tid);
         const int nk = K / BK;
+        float rsum[2] = {0.f, 0.f};
+        auto side = [&]() {
+            rsum[0] += st.a_rowpart(0);
+            rsum[1] += st.a_rowpart(1);
+        };
         st.load(0);
         st.store(lds);
+        if constexpr (SIDE_A) side();
         if (nk > 1) st.load(BK);
         __syncthreads();
         auto body = [&](int kt, auto store_next, auto load_next2) {
@@ -330,7 +350,10 @@ struct GemmBF3Big {
                 bh[s] = *(const lds_u4*)(pb + s * 32);
                 bl[s] = *(const lds_u4*)(pb + PART + s * 32);
             }
-            if constexpr (decltype(store_next)::value) st.store(lds + ((kt & 1) ^ 1) * BUF);
+            if constexpr (decltype(store_next)::value) {
+                st.store(lds + ((kt & 1) ^ 1) * BUF);
+                if constexpr (SIDE_A) side();
+            }
             if constexpr (decltype(load_next2)::value) st.load((kt + 2) * BK);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -355,6 +378,19 @@ struct GemmBF3Big {
             ++kt;
         }
         body(kt, F{}, F{});
+        if constexpr (SIDE_A) {
+            lds_f* rs_lds = (lds_f*)rs_generic;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {  // the eight threads q = 0..7 of a staged row hold its 64 k of a tile
+                float s = rsum[r];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                const int f = tid + NTH * r;
+                if ((f & 7) == 0) rs_lds[f >> 3] = s;
+            }
+            __syncthreads();
+        }
     }
     __device__ static __forceinline__ int sub_row(int i, int r) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

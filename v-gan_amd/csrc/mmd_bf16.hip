@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    G::run(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, acc);
+    G::run<false>(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, acc);
 
     const float c2 = -1.4426950408889634f / (4.f * bw);
     const float wscale = -((td.flags & VGAN_TF_NEG) ? -1.f : 1.f) * 2.f / ((float)n * (float)n * bw);
@@ -349,6 +349,61 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
     }
 }
 
+// ---- the backward product on 128x128 tiles (large problems; same decomposition, GemmBF3Big) ---------------------
+__global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
+                                                                      int ldw, const unsigned short* __restrict__ ZTh,
+                                                                      const unsigned short* __restrict__ ZTl, int kn,
+                                                                      const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
+                                                                      int ptiles, const float* __restrict__ mul, int ldmul,
+                                                                      float* __restrict__ out, int ldo, int kchunk, long slab_stride,
+                                                                      vgan_finalize_job job) {
+    using G = GemmBF3Big;
+    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
+    __shared__ float rs[128];
+    const int gx = ptiles, gy = (nr + 127) / 128, total = gx * gy;
+    if ((int)blockIdx.x >= total) {
+        if (blockIdx.y == 0) finalize_body(job);
+        return;
+    }
+    // XCD-aware order as in the 64-wide kernel: down 4 row panels, then the next feature panel
+    const int xcd = blockIdx.x % 8, kidx = blockIdx.x / 8;
+    const int q = total / 8, r8 = total % 8;
+    const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + kidx;
+    const int band = t / (4 * gx), rem = t - band * 4 * gx;
+    const int rows_in_band = min(4, gy - band * 4);
+    const int m0 = (band * 4 + rem % rows_in_band) * 128, n0 = (rem / rows_in_band) * 128;
+    const int k0 = blockIdx.y * kchunk, klen = min(kchunk, kn - k0);
+    out += blockIdx.y * slab_stride;
+    // epilogue operands requested before the main loop
+    const int col = n0 + G::sub_col(), colc = min(col, p - 1);
+    float z_pre[2][16], m_pre[2][16];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = min(m0 + G::sub_row(i2, r), nr - 1);
+            z_pre[i2][r] = Z[(long)(wrow0 + rowc) * ldz + colc];
+            m_pre[i2][r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] : 1.f;
+        }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i2][r] = 0.f;
+    if (klen > 0) G::run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, gx * 128, klen, lds, acc, rs);
+    if (col >= p) return;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = G::sub_row(i2, r), row = m0 + lrow;
+            if (row < nr) {
+                const float v = klen > 0 ? 2.f * (rs[lrow] * z_pre[i2][r] - acc[i2][r]) : 0.f;
+                out[(long)row * ldo + col] = v * m_pre[i2][r];
+            }
+        }
+}
+
 }  // namespace vgan
 
 using namespace vgan;
@@ -410,8 +465,23 @@ extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
     VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(ZTh) && aligned16(ZTl) && ldw % 8 == 0);
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
-    const int ptiles = (p + 63) / 64;
     const int kchunk = ((kn / 64 + splits - 1) / splits) * 64;
+    // large problems: 128x128 tiles (half the L2 -> LDS bytes per flop) once they fill the chip at least twice over
+    const int big_tiles = ((p + 127) / 128) * ((nr + 127) / 128);
+    if (big_tiles * splits >= 512 && kp >= ((p + 127) / 128) * 128) {
+        const int pt = (p + 127) / 128;
+        dim3 gridb(big_tiles + (finalize != nullptr ? 1 : 0), splits);
+        vgan_finalize_job jb{};
+        if (finalize != nullptr) {
+            VGAN_CHECK_ARG(finalize_job_ok(*finalize));
+            jb = *finalize;
+        }
+        hipLaunchKernelGGL(mmd_backward_bf3_big_kernel, gridb, dim3(512), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
+                           nr, p, pt, mul, ldmul, out, ldo, kchunk, (long)slab_stride, jb);
+        VGAN_CHECK_LAUNCH();
+        return VGAN_OK;
+    }
+    const int ptiles = (p + 63) / 64;
     vgan_finalize_job job{};
     if (finalize != nullptr) {
         VGAN_CHECK_ARG(finalize_job_ok(*finalize));
