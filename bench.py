@@ -119,7 +119,7 @@ def kernel_rooflines(eng):
         gname = "mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"
         add(gname, time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles, eng.Wh, eng.Wl, n + lo, eng.partial,
                                                         tile=eng.gram_tile)))
-        big_bwd = ((d + 127) // 128) * ((nl + 127) // 128) * eng.bsplits >= 512 and eng.kp >= (d + 127) // 128 * 128  # library's rule
+        big_bwd = ((d + 127) // 128) * ((nl + 127) // 128) * eng.bsplits >= 512 or os.environ.get("VGAN_BWD_TILE") == "128"  # library's rule
         add("mmd_backward_bf3_big_kernel" if big_bwd else "mmd_backward_bf3_kernel<64>", time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d,
                                                                                  eng.Z[lo:lo + nl], eng.gU, eng.bsplits, gs)))
         out["bf3_prepare_kernel"] = {"ms": time_kernel(lambda: ops.mmd_bf3_prepare(eng.Z, 2 * n, d, eng.Zh, eng.Zl, eng.ZTh, eng.ZTl))}

@@ -356,8 +356,8 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
                                                                       const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                       int ptiles, const float* __restrict__ mul, int ldmul,
                                                                       float* __restrict__ out, int ldo, int kchunk, long slab_stride,
-                                                                      vgan_finalize_job job) {
-    using G = GemmBF3Big;
+                                                                      int nb_rows, vgan_finalize_job job) {
+    using G = GemmBF3Big;  // nb_rows: rows of ZT that exist (kp); feature rows past it are clamped, their columns discarded
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     __shared__ float rs[128];
     const int gx = ptiles, gy = (nr + 127) / 128, total = gx * gy;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i2][r] = 0.f;
-    if (klen > 0) G::run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, gx * 128, klen, lds, acc, rs);
+    if (klen > 0) G::run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, nb_rows, klen, lds, acc, rs);
     if (col >= p) return;
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
@@ -468,7 +468,8 @@ extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int
     const int kchunk = ((kn / 64 + splits - 1) / splits) * 64;
     // large problems: 128x128 tiles (half the L2 -> LDS bytes per flop) once they fill the chip at least twice over
     const int big_tiles = ((p + 127) / 128) * ((nr + 127) / 128);
-    if (big_tiles * splits >= 512 && kp >= ((p + 127) / 128) * 128) {
+    static const int force_big = [] { const char* e = getenv("VGAN_BWD_TILE"); return (e && atoi(e) == 128) ? 1 : 0; }();
+    if (big_tiles * splits >= 512 || force_big) {
         const int pt = (p + 127) / 128;
         dim3 gridb(big_tiles + (finalize != nullptr ? 1 : 0), splits);
         vgan_finalize_job jb{};
@@ -477,7 +478,7 @@ extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int
             jb = *finalize;
         }
         hipLaunchKernelGGL(mmd_backward_bf3_big_kernel, gridb, dim3(512), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, pt, mul, ldmul, out, ldo, kchunk, (long)slab_stride, jb);
+                           nr, p, pt, mul, ldmul, out, ldo, kchunk, (long)slab_stride, kp, jb);
         VGAN_CHECK_LAUNCH();
         return VGAN_OK;
     }
