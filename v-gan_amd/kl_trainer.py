@@ -22,8 +22,12 @@ from .trainer import ADADELTA_EPS, ADADELTA_RHO, FlatParams, _round4
 
 
 class KLStepEngine:
-    def __init__(self, ops, generator, detector, data, batch_size, lr_D, weight_decay, penalty_weight):
+    def __init__(self, ops, generator, detector, data, batch_size, lr_D, weight_decay, penalty_weight, use_graph=True):
         self.ops = ops
+        # each step kind is captured into a HIP graph at its second use (the very first step calibrates the bandwidth
+        # eagerly); the batch indices and the noise are copied into fixed device buffers before every replay
+        self.use_graph = bool(use_graph) and data.is_cuda
+        self.graphs = {}
         self.dev = data.device
         self.data = data
         n = self.n = int(batch_size)
@@ -42,8 +46,12 @@ class KLStepEngine:
         self.fp = FlatParams(det_params, self.dev)          # detector parameters become views of one flat buffer
         self.W = [self.fp.view(self.fp.flat, 2 * k) for k in range(8)]
         self.b = [self.fp.view(self.fp.flat, 2 * k + 1) for k in range(8)]
-        self.dW = [self.fp.view(self.fp.grad, 2 * k) for k in range(8)]
-        self.db = [self.fp.view(self.fp.grad, 2 * k + 1) for k in range(8)]
+        # the weight gradients contract over the 2n stacked rows while their outputs are small: the row range is cut into
+        # slabs (partial sums, fixed order) so that a launch fills the chip; Adadelta sums the slabs itself
+        self.splits = max(1, min(8, (2 * n) // 256))
+        self.gslab = torch.zeros(self.splits, self.fp.total, dtype=torch.float32, device=self.dev)
+        self.dW = [self.fp.view(self.gslab[0], 2 * k) for k in range(8)]
+        self.db = [self.fp.view(self.gslab[0], 2 * k + 1) for k in range(8)]
         self.enc_end = self.fp.offsets[8]                   # flat range [0, enc_end) = encoder, [enc_end, total) = decoder
 
         # generator forward (no gradient)
@@ -93,10 +101,26 @@ class KLStepEngine:
         return out
 
     # ---- pieces -------------------------------------------------------------------------------------------
-    def _forward(self, idx, noise, want_grad):
-        ops, n, d = self.ops, self.n, self.d
-        self.perm.copy_(idx.to(dtype=torch.int32).view(1, n), non_blocking=True)
+    def _feed(self, idx, noise):
+        self.perm.copy_(idx.to(dtype=torch.int32).view(1, self.n), non_blocking=True)
         self.z.copy_(noise.to(dtype=torch.float32), non_blocking=True)
+
+    def _run(self, key, body):
+        """Eager until the bandwidth exists, then one captured graph per step kind."""
+        if not self.use_graph or not self.has_bw:
+            body()
+            return
+        g = self.graphs.get(key)
+        if g is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            self.graphs[key] = g
+        g.replay()
+
+    def _forward(self, want_grad):
+        ops, n, d = self.ops, self.n, self.d
         for k, m in enumerate(self.gen):
             ops.linear_forward(self.gact[k], m.weight.detach(), m.bias.detach(), self.gact[k + 1])
         ops.mask_project_forward(self.gact[4], self.data, self.perm, self.S, self.U, self.XP[:n], self.XP[n:], self.sqxp[:n], self.sqxp[n:])
@@ -117,11 +141,16 @@ class KLStepEngine:
 
     def generator_phase_step(self, idx, noise):
         """Loss evaluation of the generator phase: accumulates MMD(enc_X, enc_P, U) (src/vgan.py:295-329)."""
-        self._forward(idx, noise, want_grad=False)
+        self._feed(idx, noise)
+        self._run("g", lambda: self._forward(want_grad=False))
 
     def detector_step(self, idx, noise, train_encoder):
+        self._feed(idx, noise)
+        self._run(("d", bool(train_encoder)), lambda: self._detector_body(bool(train_encoder)))
+
+    def _detector_body(self, train_encoder):
         ops, n, d, L = self.ops, self.n, self.d, self.L
-        self._forward(idx, noise, want_grad=True)
+        self._forward(want_grad=True)
         # gradients of G = MMD - 0.1 mse_X - 0.1 mse_P  (= -loss_D)
         gs = -0.1 * 2.0 / (float(n) * d)
         for h in range(2):
@@ -133,21 +162,22 @@ class KLStepEngine:
         # decoder: layers 7..4 of the stacked chain
         g = self.dact[8]
         for k in (7, 6, 5, 4):
-            ops.linear_backward_params(g, self.act[k], self.dW[k], self.db[k])
+            ops.linear_backward_params(g, self.act[k], self.dW[k], self.db[k], self.splits, self.fp.total)
             if k > 4:
                 ops.linear_backward_input(g, self.W[k], self.dact[k])
                 g = self.dact[k]
             else:
                 ops.linear_backward_input(g, self.W[k], self.denc[0][:, :L])
-        adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=-1.0)
+        adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=-1.0, nslabs=self.splits,
+                        slab_stride=self.fp.total)
         lo = self.enc_end
-        ops.adadelta_step(self.fp.flat[lo:], self.fp.grad[lo:], self.fp.sq[lo:], self.fp.acc[lo:], **adadelta)
+        ops.adadelta_step(self.fp.flat[lo:], self.gslab[0][lo:], self.fp.sq[lo:], self.fp.acc[lo:], **adadelta)
         if train_encoder:
             ops.reduce_slabs(self.denc, 2 * n * self.Lp, 2, self.denc[0].view(-1))  # d enc = decoder path + MMD path
             g = self.dact[4]
             for k in (3, 2, 1, 0):
-                ops.linear_backward_params(g, self.act[k], self.dW[k], self.db[k])
+                ops.linear_backward_params(g, self.act[k], self.dW[k], self.db[k], self.splits, self.fp.total)
                 if k:
                     ops.linear_backward_input(g, self.W[k], self.dact[k])
                     g = self.dact[k]
-            ops.adadelta_step(self.fp.flat[:lo], self.fp.grad[:lo], self.fp.sq[:lo], self.fp.acc[:lo], **adadelta)
+            ops.adadelta_step(self.fp.flat[:lo], self.gslab[0][:lo], self.fp.sq[:lo], self.fp.acc[:lo], **adadelta)
