@@ -179,12 +179,6 @@ typedef struct vgan_finalize_job {
     int32_t ntiles, chunks, n, d;
     float weight, accum_scale;
 } vgan_finalize_job;
-/* Data-parallel step tail.  gathered: `world` records of 4 + d 64-bit words, record r = rank r's
- * {stats[4] as f64 bits, colkey[d]} (what one all-gather delivers).  Sums the statistics in rank order,
- * takes the per-column maximum of the keys, writes stats / colkey and finishes the loss as vgan_mmd_loss does. */
-int vgan_mmd_finalize_ranks(const uint64_t* gathered, int world, int d, int n, float weight, double* stats,
-                            uint64_t* colkey, float* loss, float* loss_accum, float accum_scale,
-                            uint64_t* step_counter, vgan_stream_t stream);
 /* dZ[i - wrow0, :] = 2 (rowsum(Wg_i) z_i - Wg_i . Z) for the nr rows starting at wrow0;
  * if mul != NULL the result is multiplied elementwise by mul[i - wrow0, :] (the `U * batch`
  * product rule: gU = dY * X).  Z is [ncols, p], Wg is [nr, ncols].
@@ -281,12 +275,6 @@ int vgan_noise_normal(float* z, int rows, int cols, int ld, int ones_col, uint64
  * packed is [out+1, in+1] with row stride ldp.  unpack != 0: packed -> (W, b) (rows < out only).
  * max_elems: the largest (out+1)*(in+1) in the table (sizes the grid). */
 int vgan_homogeneous_pack(const int64_t* desc, int count, int max_elems, int unpack, vgan_stream_t stream);
-/* One backward stage of that chain in ONE launch (both products read only M_k):
- *   Mout [ek1, e0] = Wt_k^T . M_k      (Wt_k is [ek, ek1], M_k is [ek, e0])
- *   G    [ek, ek1] = M_k . At_{k-1}^T  (At_{k-1} is [ek1, e0])   -- the packed gradient [dW_k | db_k]. */
-int vgan_chain_backward_stage(const float* Wt, int ldwt, const float* Mk, int ldm, const float* At,
-                              int ldat, float* Mout, int ldmo, float* G, int ldg, int ek, int ek1,
-                              int e0, vgan_stream_t stream);
 /* Adadelta for that chain without pack/unpack launches: the gradient of flat element i is
  * g_packed[pmap[i]] and the updated parameter is also stored to w_packed[pmap[i]] (pmap[i] < 0: layout
  * padding, skipped).  Same update rule as vgan_adadelta_step.

@@ -146,13 +146,6 @@ class CpuOps:
     def finalize_job(self, *args, **kw):
         return (args, kw)
 
-    def mmd_finalize_ranks(self, gathered, world, d, n, weight, stats, colkey, loss, loss_accum=None, accum_scale=1.0,
-                           step_counter=None):
-        g = gathered.reshape(world, 4 + d)
-        stats.copy_(g[:, :4].contiguous().view(torch.float64).sum(0))
-        colkey.copy_(torch.as_tensor(g[:, 4:].numpy().view(np.uint64).max(axis=0).view(np.int64)))
-        self.mmd_loss(stats, colkey, n, d, weight, loss, loss_accum, accum_scale, step_counter)
-
     def mask_backward(self, gU, S, colkey, pen_weight, row_offset, dlogits, nslabs=1, slab_stride=0):
         s = _np(S).astype(np.float32)
         n, d = s.shape
@@ -350,10 +343,6 @@ class CpuOps:
         p.copy_(torch.as_tensor(pn))
         sq.copy_(torch.as_tensor(sn))
         acc.copy_(torch.as_tensor(an))
-
-    def chain_backward_stage(self, Wt, Mk, At, Mout, G):
-        Mout.copy_(torch.as_tensor(_np(Wt).astype(np.float64).T @ _np(Mk).astype(np.float64)))
-        G.copy_(torch.as_tensor(_np(Mk).astype(np.float64) @ _np(At).astype(np.float64).T))
 
     def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0,
                              next_noise=None, noise_cols=0, noise_ones_col=-1, seed=0, step_counter=None):

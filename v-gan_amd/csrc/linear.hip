@@ -121,45 +121,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_bwd_params_ks
         if (row < out && col < in) dW[(long)row * lddw + col] = o[rr];
     }
 }
-// One backward stage of the collapsed generator chain in ONE launch (the two products only share their input M_k):
-//   workgroups [0, nbm)   : M_{k-1} = Wt_k^T . M_k          (tall-skinny, K = e_k)      -> Mout [e_{k-1}, e_0]
-//   workgroups [nbm, ...) : Gt_k    = M_k . At_{k-1}^T      (64x64 tiles, K = e_0)      -> G    [e_k, e_{k-1}]
-template <int VEC>
-__global__ __launch_bounds__(kBlock, 2) void chain_backward_stage_kernel(const float* __restrict__ Wt, int ldwt,
-                                                                        const float* __restrict__ Mk, int ldm,
-                                                                        const float* __restrict__ At, int ldat,
-                                                                        float* __restrict__ Mout, int ldmo, float* __restrict__ G,
-                                                                        int ldg, int ek, int ek1, int e0, int nbm, int gx_m) {
-    using GK = GemmTileKS<KSBK, MC, MC, VEC>;
-    using GT64 = GemmTile<LBM, LBN, LBK, KC, KC, VEC>;
-    constexpr int kLds = GK::kLdsFloats > GT64::kLdsFloats ? GK::kLdsFloats : GT64::kLdsFloats;
-    __shared__ __attribute__((aligned(16))) float lds[kLds];
-    if ((int)blockIdx.x < nbm) {  // block-uniform
-        const int m0 = (blockIdx.x / gx_m) * 32, n0 = (blockIdx.x % gx_m) * 32;
-        float o[GK::NR];
-        GK::run(Wt, ldwt, Mk, ldm, m0, n0, ek1, e0, ek, lds, o);  // A(i, k) = Wt[k][i], B(j, k) = Mk[k][j]
-        const int col = n0 + GK::col_of();
-#pragma unroll
-        for (int rr = 0; rr < GK::NR; ++rr) {
-            const int row = m0 + GK::row_of(rr);
-            if (row < ek1 && col < e0) Mout[(long)row * ldmo + col] = o[rr];
-        }
-    } else {
-        const int b = blockIdx.x - nbm;
-        const int gx = (ek1 + LBN - 1) / LBN;
-        const int m0 = (b / gx) * LBM, n0 = (b % gx) * LBN;
-        f32x16 acc[1][1];
-        zero_acc(acc);
-        GT64::template run<false>(Mk, ldm, At, ldat, m0, n0, ek, ek1, e0, lds, nullptr, acc);
-        const int col = n0 + GT64::sub_col(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + GT64::sub_row(0, r);
-            if (row < ek && col < ek1) G[(long)row * ldg + col] = acc[0][0][r];
-        }
-    }
-}
-
 // heuristic: few 64x64 tiles and a long contraction -> the K loop of a tile is the critical path
 static inline bool use_ks(int rows, int cols, int k) {
     const long tiles64 = (long)((rows + 63) / 64) * ((cols + 63) / 64);
@@ -236,26 +197,6 @@ extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const floa
     if (x_nslabs > 1) { if (vec) VGAN_BWP(4, true); else VGAN_BWP(1, true); }
     else { if (vec) VGAN_BWP(4, false); else VGAN_BWP(1, false); }
 #undef VGAN_BWP
-    VGAN_CHECK_LAUNCH();
-    return VGAN_OK;
-}
-
-extern "C" int vgan_chain_backward_stage(const float* Wt, int ldwt, const float* Mk, int ldm, const float* At, int ldat, float* Mout,
-                                         int ldmo, float* G, int ldg, int ek, int ek1, int e0, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(Wt && Mk && At && Mout && G && ek > 0 && ek1 > 0 && e0 > 0);
-    VGAN_CHECK_ARG(ldwt >= ek1 && ldm >= e0 && ldat >= e0 && ldmo >= e0 && ldg >= ek1);
-    const bool vec = (ek % 4 == 0) && (ek1 % 4 == 0) && (e0 % 4 == 0) && (ldwt % 4 == 0) && (ldm % 4 == 0) && (ldat % 4 == 0) &&
-                     aligned16(Wt) && aligned16(Mk) && aligned16(At);
-    const int gx_m = (e0 + 31) / 32, nbm = gx_m * ((ek1 + 31) / 32);
-    const int nbg = ((ek + LBM - 1) / LBM) * ((ek1 + LBN - 1) / LBN);
-    dim3 grid(nbm + nbg), block(kBlock);
-    hipStream_t s = (hipStream_t)stream;
-    if (vec)
-        hipLaunchKernelGGL(chain_backward_stage_kernel<4>, grid, block, 0, s, Wt, ldwt, Mk, ldm, At, ldat, Mout, ldmo, G, ldg, ek, ek1, e0,
-                           nbm, gx_m);
-    else
-        hipLaunchKernelGGL(chain_backward_stage_kernel<1>, grid, block, 0, s, Wt, ldwt, Mk, ldm, At, ldat, Mout, ldmo, G, ldg, ek, ek1, e0,
-                           nbm, gx_m);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -180,44 +180,6 @@ __global__ void mmd_loss_kernel(const double* __restrict__ stats, const unsigned
 // then the loss (replaces mmd_reduce + colmax_final + mmd_loss, three latency-bound launches).
 __global__ __launch_bounds__(1024) void mmd_finalize_kernel(vgan_finalize_job job) { finalize_body(job); }
 
-// ---- data-parallel step tail: every rank contributes one record {Sxx, Sxy, Syy, sumL (f64 bits) | colkey[d]} of
-// 4 + d 64-bit words (ONE all-gather instead of an all-reduce(SUM) plus an all-reduce(MAX)); this kernel folds the
-// `world` records -- sums in rank order, so every rank computes bit-identical results -- and finishes the loss.
-__global__ __launch_bounds__(1024) void mmd_finalize_ranks_kernel(const unsigned long long* __restrict__ gathered, int world, int d,
-                                                                 int n, float weight, double* __restrict__ stats,
-                                                                 unsigned long long* __restrict__ colkey, float* __restrict__ loss,
-                                                                 float* __restrict__ loss_accum, float accum_scale,
-                                                                 unsigned long long* __restrict__ step_counter) {
-    __shared__ double red[16];
-    const long rec = 4 + (long)d;
-    double pen = 0.0;
-    for (int j = threadIdx.x; j < d; j += blockDim.x) {
-        unsigned long long b = 0ull;
-        for (int r = 0; r < world; ++r) {
-            const unsigned long long k = gathered[r * rec + 4 + j];
-            b = k > b ? k : b;
-        }
-        colkey[j] = b;
-        pen += 1.0 - (double)colkey_value(b);
-    }
-    pen = wave_sum(pen);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t[4] = {0, 0, 0, 0};
-        for (int r = 0; r < world; ++r)
-            for (int q = 0; q < 4; ++q) t[q] += __longlong_as_double((long long)gathered[r * rec + q]);
-        for (int q = 0; q < 4; ++q) stats[q] = t[q];
-        double p = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) p += red[w];
-        const double nn = (double)n * (double)n;
-        const double v = (t[0] - 2.0 * t[1] + t[2]) / nn + (double)weight * p / (double)d;
-        loss[0] = (float)v;
-        if (loss_accum) loss_accum[0] += (float)(v * (double)accum_scale);
-        if (step_counter) step_counter[0] += 1ull;
-    }
-}
-
 // ---- backward: dZ_i = 2 (rowsum(Wg_i) z_i - (Wg . Z)_i), optionally times mul ---------------
 // A = Wg [nr, ncols] (KC), B(j = feature, k = Z row) = Z[k*ldz + j] (MC).
 template <int VEC, int KW>
@@ -484,18 +446,6 @@ extern "C" int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int
                                 accum_scale};
     VGAN_CHECK_ARG(finalize_job_ok(job));
     hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, job);
-    VGAN_CHECK_LAUNCH();
-    return VGAN_OK;
-}
-
-extern "C" int vgan_mmd_finalize_ranks(const uint64_t* gathered, int world, int d, int n, float weight, double* stats, uint64_t* colkey,
-                                       float* loss, float* loss_accum, float accum_scale, uint64_t* step_counter,
-                                       vgan_stream_t stream) {
-    VGAN_CHECK_ARG(gathered && world > 0 && d > 0 && n > 0 && stats && colkey && loss);
-    hipLaunchKernelGGL(mmd_finalize_ranks_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
-                       reinterpret_cast<const unsigned long long*>(gathered), world, d, n, weight, stats,
-                       reinterpret_cast<unsigned long long*>(colkey), loss, loss_accum, accum_scale,
-                       reinterpret_cast<unsigned long long*>(step_counter));
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

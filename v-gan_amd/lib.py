@@ -51,7 +51,6 @@ SIGNATURES = {
     "vgan_mmd_reduce": (_i, [_p, _p, _i, _p, _i, _p]),
     "vgan_mmd_set_bandwidth": (_i, [_p, _i, _p, _p]),
     "vgan_mmd_loss": (_i, [_p, _p, _i, _i, _f, _p, _p, _f, _p, _p]),
-    "vgan_mmd_finalize_ranks": (_i, [_p, _i, _i, _i, _f, _p, _p, _p, _p, _f, _p, _p]),
     "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p, _p]),
     "vgan_mmd_bf3_prepare": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
@@ -60,7 +59,6 @@ SIGNATURES = {
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_noise_normal": (_i, [_p, _i, _i, _i, _i, _u64, _p, _u64, _p]),
     "vgan_homogeneous_pack": (_i, [_p, _i, _i, _i, _p]),
-    "vgan_chain_backward_stage": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _u64, _p, _p]),
     "vgan_gemm_grouped": (_i, [_p, _i, _p]),
     "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p]),

@@ -163,13 +163,6 @@ class HipOps:
         return _lib.FinalizeJob(_ptr(partial), _ptr(tiles), _ptr(colpart), _ptr(colkey), _ptr(stats), _ptr(loss), _ptr(loss_accum),
                                 _ptr(step_counter), tiles.shape[0], int(chunks), int(n), int(d), float(weight), float(accum_scale))
 
-    def mmd_finalize_ranks(self, gathered, world, d, n, weight, stats, colkey, loss, loss_accum=None, accum_scale=1.0,
-                           step_counter=None):
-        assert gathered.dtype == torch.int64 and gathered.numel() >= world * (4 + d)
-        _lib.check(self.lib.vgan_mmd_finalize_ranks(_ptr(gathered), int(world), int(d), int(n), float(weight), _ptr(stats),
-                                                    _ptr(colkey), _ptr(loss), _ptr(loss_accum), float(accum_scale),
-                                                    _ptr(step_counter), self._stream()), "vgan_mmd_finalize_ranks")
-
     def mask_from_softmax(self, S, U):
         _mat(S, "S"), _mat(U, "U")
         n, d = S.shape
@@ -309,17 +302,6 @@ class HipOps:
         _lib.check(self.lib.vgan_adadelta_step(_ptr(p), _ptr(g), int(nslabs), int(slab_stride), _ptr(sq), _ptr(acc), p.numel(),
                                                float(lr), float(rho), float(eps),
                                                float(weight_decay), float(grad_scale), self._stream()), "vgan_adadelta_step")
-
-    def chain_backward_stage(self, Wt, Mk, At, Mout, G):
-        """Mout = Wt^T . Mk and G = Mk . At^T in one launch (collapsed generator backward, see include/vgan_hip.h)."""
-        for t, nm in ((Wt, "Wt"), (Mk, "Mk"), (At, "At"), (Mout, "Mout"), (G, "G")):
-            _mat(t, nm)
-        ek, ek1 = Wt.shape
-        e0 = Mk.shape[1]
-        assert Mk.shape[0] == ek and At.shape == (ek1, e0) and Mout.shape == (ek1, e0) and G.shape == (ek, ek1)
-        _lib.check(self.lib.vgan_chain_backward_stage(_ptr(Wt), Wt.stride(0), _ptr(Mk), Mk.stride(0), _ptr(At), At.stride(0),
-                                                      _ptr(Mout), Mout.stride(0), _ptr(G), G.stride(0), ek, ek1, e0, self._stream()),
-                   "vgan_chain_backward_stage")
 
     def adadelta_step_packed(self, p, pmap, g_packed, w_packed, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0,
                              next_noise=None, noise_cols=0, noise_ones_col=-1, seed=0, step_counter=None):

@@ -1,7 +1,7 @@
 """Step engine of ``VGAN_no_kl.fit`` (reference: src/vgan.py:597-621) over a kernel provider.
 
 One step = noise -> Generator_big (4 Linear) -> upper_softmax -> U*X -> MMDLossConstrained ->
-backward -> Adadelta, launched as ~20 asynchronous kernels on caller-owned, preallocated HBM
+backward -> Adadelta, launched as 11 asynchronous kernels (collapsed generator, bf16x3) on caller-owned, preallocated HBM
 buffers and (on a GPU) replayed from one captured HIP graph per step.  Nothing in a step
 synchronises the host: the loss is accumulated on the device and read once per epoch.
 
@@ -162,11 +162,6 @@ class NoKLStepEngine:
                 pmap[ow:ow + wk * wk1] = (poff[k - 1] + r + torch.arange(wk1, dtype=torch.int32)[None, :]).reshape(-1)
                 pmap[ob:ob + wk] = (poff[k - 1] + r + wk1).reshape(-1)
             self.pmap = pmap.to(self.dev)
-            # The M products have long contractions (batch rows, d, 8L) and tiny outputs; the library runs them on its
-            # tall-skinny kernel (32x32 tiles, K split across the waves of a workgroup), so no row slabs are needed.
-            # (Slabs + a reduction launch, or slab-summing staging loads, were both measured slower.)
-            self.msplit = {4: 1, 3: 1, 2: 1, 1: 1}
-            self.Mslab = {k: (torch.zeros(s, e[k] * e[0], **f32) if s > 1 else None) for k, s in self.msplit.items()}
             self.pack_layers = [(self.W[k - 1], self.b[k - 1], self.Wt[k]) for k in range(1, 5)]
             self.unpack_layers = [(self.fp.view(self.fp.grad, 2 * (k - 1)), self.fp.view(self.fp.grad, 2 * (k - 1) + 1), self.Gt[k])
                                   for k in range(1, 5)]
@@ -281,17 +276,6 @@ class NoKLStepEngine:
         ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
         ops.linear_forward(self.za, At[4][:self.d], None, self.logits)
 
-    def _m_operand(self, k, reduced):
-        """M_k as a GEMM operand: (tensor, nslabs, slab_stride).  The slabs are reduced by their own launch: letting the
-        consumers' staging loads sum them (the C ABI supports it) was measured 3x SLOWER at 8 slabs (20.9 vs 7.5 us per
-        product: every K tile re-reads all slabs), so `reduced=False` is only honoured for two slabs."""
-        if self.msplit[k] == 1:
-            return self.M[k], 1, 0
-        if reduced or self.msplit[k] > 2:
-            self.ops.reduce_slabs(self.Mslab[k], self.e[k] * self.e[0], self.msplit[k], self.M[k].view(-1))
-            return self.M[k], 1, 0
-        return self.Mslab[k][0].view(self.e[k], self.e[0]), self.msplit[k], self.e[k] * self.e[0]
-
     def _generator_backward_update(self, dist):
         """dlogits -> parameter gradients -> (all-reduce) -> Adadelta."""
         ops = self.ops
@@ -316,10 +300,9 @@ class NoKLStepEngine:
             return
         e, d = self.e, self.d
         # M4[:d] = dlogits^T . [z|1]   (rows >= d stay zero: the homogeneous output coordinate carries no gradient)
-        tgt = self.Mslab[4][0].view(e[4], e[0]) if self.msplit[4] > 1 else self.M[4]
-        ops.linear_backward_params(self.dlogits, self.z_own, tgt[:d], None, self.msplit[4], e[4] * e[0])
-        if self.msplit[4] > 1:
-            self._m_operand(4, reduced=True)
+        # (the library runs this long contraction on its tall-skinny 16-wave tiles; row slabs + a reduction launch, or
+        # slab-summing staging loads in the consumers, were both measured slower)
+        ops.linear_backward_params(self.dlogits, self.z_own, self.M[4][:d], None)
         if dist:
             dist.all_reduce(self.M[4], group=self.group)
         # M_{k-1} = Wt_k^T M_k, i.e. M_3 = Wt_4^T M_4, M_2 = B_3^T M_4, M_1 = B_2^T M_4 (At_0 = I: Gt_1 IS M_1), and
