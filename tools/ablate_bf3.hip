@@ -1,5 +1,5 @@
 // Ablation micro-benchmark of the split-bf16 tile main loop (tools only; not part of the library).
-// Build variants with -DVGAN_ABLATE_NO_GLOBAL / _NO_MFMA / _ONE_PRODUCT / _NO_LDS_STORE / _NO_BARRIER, -DTBK=32|64, -DKSP=true, -DOCC_=n.
+// Build variants with -DVGAN_ABLATE_NO_GLOBAL / _NO_MFMA / _ONE_PRODUCT / _NO_LDS_STORE / _NO_BARRIER, -DTBK=32|64, -DOCC_=n.
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -9,14 +9,12 @@ namespace vgan { void set_error(const char*, ...) {} }
 #ifndef TBK
 #define TBK 64
 #endif
-#ifndef KSP
-#define KSP false
-#endif
+
 #ifndef OCC_
 #define OCC_ 2
 #endif
 __global__ __launch_bounds__(kBlock, OCC_) void k(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out) {
-    using G = GemmBF3<TBK, KSP>;
+    using G = GemmBF3<TBK>;
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     const int r0 = (blockIdx.x / tiles_per_row) * 64, c0 = (blockIdx.x % tiles_per_row) * 64;
     f32x16 acc;

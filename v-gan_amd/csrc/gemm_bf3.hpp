@@ -17,14 +17,10 @@ typedef __attribute__((address_space(3))) unsigned short lds_u16;
 // Gram tiles of the metric's configuration are resident at once -- measured SLOWER (28.3 vs 25.5 us; the CUs that are
 // dealt three tiles are throughput-bound, not waiting for a second round), kept behind VGAN_BF3_BK=32 for measurement.
 //
-// KSPLIT (BK = 64 only): the four waves do not split the 64x64 output into quadrants; wave w computes the WHOLE tile for
-// k16 step w of every K tile (4 accumulators) and the partial tiles are summed through LDS once, after the loop, so
-// that each wave ends up with the quadrant it would have owned.  The main loop is bound by the LDS pipe (ablation in
-// profiles/README.md: dropping the MFMAs changes nothing, dropping the LDS stores saves a third): per K tile the quadrant
-// form reads 64 KB of fragments + writes 32 KB, the K-split form reads 32 KB + writes 32 KB.
-template <int BK_, bool KSPLIT = false>
+// Variants measured and dropped (profiles/README.md): K tile 32 with three workgroups per CU (slower, bank-conflicted), the
+// four waves splitting K instead of the tile (half the fragment reads but longer MFMA chains and a combine: slower).
+template <int BK_>
 struct GemmBF3 {
-    static_assert(!KSPLIT || BK_ == 64, "the K split deals the four k16 steps of a 64-wide K tile to the four waves");
     static constexpr int BK = BK_;                 // bf16 elements of K per tile
     static constexpr int NR = BK / 32;             // 16-byte pieces per thread and operand part
     static constexpr int QPR = BK / 8;             // 16-byte pieces per row
@@ -103,53 +99,8 @@ struct GemmBF3 {
         if constexpr (SIDE_A) side();
         if (nk > 1) st.load(BK);
         __syncthreads();
-        f32x16 part[2][2];  // KSPLIT: this wave's partial tile
-        if constexpr (KSPLIT) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
-        }
         auto body = [&](int kt, auto store_next, auto load_next2) {
             const lds_c* buf = lds + (kt & 1) * BUF;
-            if constexpr (KSPLIT) {
-                const lds_c* pa = buf + fi * ROWB + wave * 32 + fh * 16;  // k16 step = wave
-                const lds_c* pb = pa + 2 * PART;
-                u32x4 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    ah[i] = *(const lds_u4*)(pa + i * 32 * ROWB);
-                    al[i] = *(const lds_u4*)(pa + PART + i * 32 * ROWB);
-                    bh[i] = *(const lds_u4*)(pb + i * 32 * ROWB);
-                    bl[i] = *(const lds_u4*)(pb + PART + i * 32 * ROWB);
-                }
-                if constexpr (decltype(store_next)::value) {
-#ifndef VGAN_ABLATE_NO_LDS_STORE
-                    st.store(lds + ((kt & 1) ^ 1) * BUF);
-#endif
-                    if constexpr (SIDE_A) side();
-                }
-#ifndef VGAN_ABLATE_NO_GLOBAL
-                if constexpr (decltype(load_next2)::value) st.load((kt + 2) * BK);
-#endif
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xl = __builtin_bit_cast(bf16x8, al[i]);
-                        const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[j]), yl = __builtin_bit_cast(bf16x8, bl[j]);
-                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, part[i][j], 0, 0, 0);  // small terms first
-                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, part[i][j], 0, 0, 0);
-                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, part[i][j], 0, 0, 0);
-                    }
-                __builtin_amdgcn_iglp_opt(0);
-#ifndef VGAN_ABLATE_NO_BARRIER
-                __syncthreads();
-#endif
-                return;
-            }
             const lds_c* pa = buf + (wm0 + fi) * ROWB + fh * 16;
             const lds_c* pb = buf + 2 * PART + (wn0 + fi) * ROWB + fh * 16;
             u32x4 ah[KS], al[KS], bh[KS], bl[KS];
@@ -197,41 +148,6 @@ struct GemmBF3 {
             ++kt;
         }
         body(kt, F{}, F{});
-        if constexpr (KSPLIT) {
-            // the staging buffers are free (the last body ended in a barrier): slot [quadrant q][wave v][g] of 64 x 16 B
-            typedef __attribute__((address_space(3))) f32x4 lds_v4;
-            lds_v4* red = (lds_v4*)lds;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q != wave) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x16& src = part[q >> 1][q & 1];
-                        red[((q * 4 + wave) * 4 + g) * 64 + lane] = f32x4{src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
-                    }
-                }
-            __syncthreads();
-            // fixed summation order v = 0..3 (own partial in its place): the result does not depend on which wave sums
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    f32x4 x;
-                    if (v == wave) {
-                        f32x16 own;
-                        own = wave == 0 ? part[0][0] : wave == 1 ? part[0][1] : wave == 2 ? part[1][0] : part[1][1];
-                        x = f32x4{own[4 * g], own[4 * g + 1], own[4 * g + 2], own[4 * g + 3]};
-                    } else {
-                        x = red[((wave * 4 + v) * 4 + g) * 64 + lane];
-                    }
-                    t = v == 0 ? x : t + x;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * g + e] += t[e];
-            }
-            __syncthreads();  // rs_lds / the caller may reuse LDS
-        }
         if constexpr (SIDE_A) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) {

@@ -408,15 +408,6 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
 
 using namespace vgan;
 
-// K tile of the split-bf16 kernels (measurement knob; see the GemmBF3 comment)
-static int bf3_bk() {
-    static const int v = [] {
-        const char* e = getenv("VGAN_BF3_BK");
-        return (e != nullptr && atoi(e) == 32) ? 32 : 64;  // 64 measured faster (Gram 25.5 vs 28.3 us, backward 24.3 vs 35.8)
-    }();
-    return v;
-}
-
 extern "C" int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,
                                     uint16_t* ZTl, int kn, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Z && Zh && Zl && rows > 0 && p > 0 && ldz >= p && kp >= p && kp % 64 == 0 && aligned16(Zh) && aligned16(Zl));
@@ -447,11 +438,8 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
     if (tile == 128)
         hipLaunchKernelGGL(mmd_gram_bf3_big_kernel, dim3(ntiles + extra), dim3(512), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
                            reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
-    else if (bf3_bk() == 64)
-        hipLaunchKernelGGL(mmd_gram_bf3_kernel<64>, dim3(ntiles + extra), dim3(kBlock), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
-                           reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
     else
-        hipLaunchKernelGGL(mmd_gram_bf3_kernel<32>, dim3(ntiles + extra), dim3(kBlock), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
+        hipLaunchKernelGGL(mmd_gram_bf3_kernel<64>, dim3(ntiles + extra), dim3(kBlock), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
                            reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
@@ -489,11 +477,7 @@ extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int
         job = *finalize;
     }
     dim3 grid(ptiles * ((nr + 63) / 64) + (finalize != nullptr ? 1 : 0), splits);
-    if (bf3_bk() == 64)
         hipLaunchKernelGGL(mmd_backward_bf3_kernel<64>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride, job);
-    else
-        hipLaunchKernelGGL(mmd_backward_bf3_kernel<32>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
                            nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride, job);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
