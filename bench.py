@@ -29,6 +29,8 @@ import torch  # noqa: E402
 
 N_BATCH, D_FEAT, EPOCH_BATCHES, CONFIG = 1024, 784, 16, "c3"
 WORKLOADS = {  # --workload: the metric is quoted on c3; c4 / c5 are the larger BASELINE.json configurations (extra lines)
+    "c1": (128, 20, 16, "configs[0]: 2-Gaussian mixture, d=20, batch=128 (VGAN_no_kl step; launch-latency bound)"),
+    "c2": (512, 166, 5, "configs[1]: ADBench 'musk' stand-in, d=166, batch=512 (VGAN_no_kl step)"),
     "c3": (1024, 784, 16, "configs[2]: MNIST-pixels-as-features stand-in, d=784, batch=1024 (VGAN_no_kl step)"),
     "c4": (4096, 2048, 4, "configs[3]: synthetic tabular, d=2048, batch=4096 (VGAN_no_kl step)"),
     "c5": (8192, 4096, 4, "configs[4]: synthetic tabular, d=4096, batch=8192, 5-bandwidth RBF (VGAN_no_kl step)"),
@@ -219,7 +221,7 @@ def main():
     N_BATCH, D_FEAT, EPOCH_BATCHES, WORKLOAD = WORKLOADS[CONFIG]
     if args.path == "kl":
         return bench_kl(args)
-    if CONFIG != "c3":
+    if CONFIG in ("c4", "c5"):
         args.steps, args.warmup = min(args.steps, 200), min(args.warmup, 8)
         args.no_cpu_baseline = args.no_cpu_baseline or CONFIG == "c5"  # N = 16384: ~17 GB and ~15 s per CPU step
     world = int(os.environ.get("WORLD_SIZE", "1"))
