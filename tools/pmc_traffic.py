@@ -13,7 +13,8 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = ["mmd_gram_kernel", "mmd_backward_kernel", "mmd_gram_bf3_kernel", "mmd_backward_bf3_kernel", "bf3_prepare_kernel"]
+KERNELS = ["mmd_gram_kernel", "mmd_backward_kernel", "mmd_gram_bf3_kernel", "mmd_backward_bf3_kernel", "mmd_gram_bf3_big_kernel",
+           "mmd_backward_bf3_big_kernel", "bf3_prepare_kernel", "mask_forward_bf3_kernel"]
 
 
 def fold(d):
@@ -42,7 +43,8 @@ def main():
                           "as is; separate --pmc passes on tools/kbench.py"}
         if k in sq:
             out[k]["sq_counters"] = {c: sum(v) / len(v) for c, v in sq[k].items() if c != "_name"}
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    name = os.environ.get("VGAN_TRAFFIC_JSON", "traffic.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items()}))
 
