@@ -182,11 +182,13 @@ class NoKLStepEngine:
         self.Z = torch.zeros(2 * n, dp, **f32)
         self.sqn = torch.zeros(2 * n, **f32)
         self.Wg = torch.zeros(nl, 2 * n, **f32)
-        # the backward GEMM contracts over the 2n rows of Z; it can be sliced into row slabs that the mask-backward kernel
-        # sums (VGAN_BWD_SPLITS), but its 512-thread K-split workgroups already hold four waves per SIMD: default 1
-        # split-K slabs of the backward product: the split-bf16 kernel is bound by load latency (one 64x64 tile per CU,
-        # 32 dependent K tiles), so two independent K halves per CU pay; the fp32 kernel is MFMA-bound (all counts equal)
-        self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", "2" if self.bf3 else "1")))
+        # The backward GEMM contracts over the 2n rows of Z; it can be sliced into row slabs that the mask-backward kernel
+        # sums.  Measured at c3: 2 slabs pay for the split-bf16 kernel (24.3 vs 29.6 us; 3 and 4 spill into a second round
+        # of workgroups), none do for the fp32 kernel.  Small problems have only a handful of output tiles with a long K
+        # loop each (c2: 24 tiles, 26 us of an 84 us step), so the slab count also grows until the launch fills the chip.
+        out_tiles = ((nl + 63) // 64) * ((d + 63) // 64)
+        auto_splits = max(2 if self.bf3 else 1, min(8, 256 // max(out_tiles, 1), max(1, (2 * n) // 256)))
+        self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", str(auto_splits))))
         self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
         self.gU = self.gU_slabs[0]
         self.dlogits = torch.zeros(nl, d, **f32)
