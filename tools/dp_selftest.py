@@ -17,7 +17,8 @@ torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
 
-for graph in (False, True):
+only = os.environ.get("VGAN_SELFTEST_ONLY_G")  # profiling aid: skip everything but the 1/G shard emulation
+for graph in (() if only else (False, True)):
     eng, data, params = bench.build_engine(rank, world, graph, force_exchange=True)
     losses = []
     for t in range(6):
@@ -34,7 +35,7 @@ for graph in (False, True):
 # A lower bound for the G-GPU step (the real all-reduce latency comes on top); numerics are meaningless here.
 import time
 if world == 1:
-    for G in (1, 2, 4, 8):
+    for G in ((int(only),) if only else (1, 2, 4, 8)):
         eng, data, params = bench.build_engine(0, G, True, force_exchange=True)
         bench.run_steps(eng, 64, 0)
         torch.cuda.synchronize()
