@@ -191,7 +191,9 @@ class NoKLStepEngine:
         self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", str(auto_splits))))
         self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
         self.gU = self.gU_slabs[0]
-        self.dlogits = torch.zeros(nl, d, **f32)
+        # [nl, d] view of a zero-padded [nl, dp] buffer: the M_4 product reads the padded matrix (vector loads for any d)
+        self.dlogits_pad = torch.zeros(nl, dp, **f32)
+        self.dlogits = self.dlogits_pad[:, :d]
         # MMD arithmetic: "fp32" (fp32 MFMA, default) or "bf16x3" (split-bf16 operands on the bf16 MFMA, see
         # csrc/mmd_bf16.hip: ~3e-7 relative on a Gram entry at K = 784, a third of the time)
         if self.precision == "bf16x3":
@@ -304,7 +306,7 @@ class NoKLStepEngine:
         # M4[:d] = dlogits^T . [z|1]   (rows >= d stay zero: the homogeneous output coordinate carries no gradient)
         # (the library runs this long contraction on its tall-skinny 16-wave tiles; row slabs + a reduction launch, or
         # slab-summing staging loads in the consumers, were both measured slower)
-        ops.linear_backward_params(self.dlogits, self.z_own, self.M[4][:d], None)
+        ops.linear_backward_params(self.dlogits_pad, self.z_own, self.M[4][:self.dp], None)  # pad columns are zero: rows d.. of M_4 too
         if dist:
             dist.all_reduce(self.M[4], group=self.group)
         # M_{k-1} = Wt_k^T M_k, i.e. M_3 = Wt_4^T M_4, M_2 = B_3^T M_4, M_1 = B_2^T M_4 (At_0 = I: Gt_1 IS M_1), and
