@@ -69,7 +69,8 @@ class KLStepEngine:
         self.encZp = self.encZ.as_strided((2 * n, self.Lp), (self.Lp, 1))
         # gradients of the activations; at the encoder output two contributions meet (MMD and decoder): two slabs
         self.dact = [None] + [torch.zeros(2 * n, w, **f32) for w in widths]
-        self.denc = torch.zeros(2, 2 * n, self.Lp, **f32)
+        self.msplits = max(1, min(8, (2 * n) // 256))           # split-K slabs of the MMD backward (32 output tiles only)
+        self.denc = torch.zeros(1 + self.msplits, 2 * n, self.Lp, **f32)
         self.dact[4] = self.denc[0][:, :L]
         self.mse_part = torch.zeros(2, (n + 3) // 4, dtype=torch.float64, device=self.dev)
         # MMD on the encodings (gradient for all 2n rows)
@@ -150,7 +151,8 @@ class KLStepEngine:
 
     def _detector_body(self, train_encoder):
         ops, n, d, L = self.ops, self.n, self.d, self.L
-        self._forward(want_grad=True)
+        # the MMD term reaches only the encoder: with the encoder frozen neither its gradient weights nor its backward run
+        self._forward(want_grad=train_encoder)
         # gradients of G = MMD - 0.1 mse_X - 0.1 mse_P  (= -loss_D)
         gs = -0.1 * 2.0 / (float(n) * d)
         for h in range(2):
@@ -158,7 +160,8 @@ class KLStepEngine:
             ops.mse_grad(self.XP[rows, :d], self.act[8][rows], gs, self.mse_part[h], self.dact[8][rows])
             ops.sum_f64(self.mse_part[h], (n + 3) // 4, 1.0 / (float(n) * d), self.mse[h:h + 1])
             ops.sum_f64(self.mse_part[h], (n + 3) // 4, 1.0 / (float(n) * d), self.acc_mse[h:h + 1], accumulate=True)
-        ops.mmd_backward(self.Wg, self.encZp, 0, 2 * n, 2 * n, self.Lp, None, self.denc[1])
+        if train_encoder:
+            ops.mmd_backward(self.Wg, self.encZp, 0, 2 * n, 2 * n, self.Lp, None, self.denc[1], self.msplits, 2 * n * self.Lp)
         # decoder: layers 7..4 of the stacked chain
         g = self.dact[8]
         for k in (7, 6, 5, 4):
@@ -166,14 +169,14 @@ class KLStepEngine:
             if k > 4:
                 ops.linear_backward_input(g, self.W[k], self.dact[k])
                 g = self.dact[k]
-            else:
+            elif train_encoder:
                 ops.linear_backward_input(g, self.W[k], self.denc[0][:, :L])
         adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=-1.0, nslabs=self.splits,
                         slab_stride=self.fp.total)
         lo = self.enc_end
         ops.adadelta_step(self.fp.flat[lo:], self.gslab[0][lo:], self.fp.sq[lo:], self.fp.acc[lo:], **adadelta)
         if train_encoder:
-            ops.reduce_slabs(self.denc, 2 * n * self.Lp, 2, self.denc[0].view(-1))  # d enc = decoder path + MMD path
+            ops.reduce_slabs(self.denc, 2 * n * self.Lp, 1 + self.msplits, self.denc[0].view(-1))  # d enc = decoder path + MMD slabs
             g = self.dact[4]
             for k in (3, 2, 1, 0):
                 ops.linear_backward_params(g, self.act[k], self.dW[k], self.db[k], self.splits, self.fp.total)
