@@ -12,13 +12,81 @@ step kinds, both launched here kernel by kernel on preallocated buffers, without
   generator-phase step (src/vgan.py:295-329): the same forward, loss_G = MMD(enc_X, enc_P, U); nothing is updated.
 
 The stacked rows are exactly the [X ; Y] operand layout of the MMD kernels (p = L), and both detector passes share
-one set of launches.  Gradients are formed for  -loss_D = MMD - 0.1 mse - 0.1 mse  (the sign the kernels produce) and
+one set of launches.  Encoder and decoder have no activation between their Linear layers either (src/models/Detector.py:8-13,
+24-29), so each is run as ONE matrix chain in homogeneous coordinates, exactly like the generator of the no-kl engine
+(trainer.py): enc = [x|1] . (Et_4 Et_3 Et_2 Et_1)^T, dec = [enc|1] . (Dt_4 .. Dt_1)^T, weight gradients from
+M_4 = dy^T [x|1] through M_{k-1} = Wt_k^T M_k and [dW_k | db_k] = M_k At_{k-1}^T -- ~1 GFLOP per step instead of the ~9
+of eight layered GEMMs over the 2n rows.  Gradients are formed for  -loss_D = MMD - 0.1 mse - 0.1 mse  (the sign the kernels produce) and
 Adadelta is called with grad_scale = -1.  Reference quirks kept: the encoder is frozen for good by the first generator
 phase (src/vgan.py:319-320) while the decoder is re-enabled by every detector step (:257-258).
 """
 import torch
 
 from .trainer import ADADELTA_EPS, ADADELTA_RHO, FlatParams, _round4
+
+
+class CollapsedChain:
+    """Four bias-Linear layers (parameters 2*k0 .. 2*k0+7 of a FlatParams, layer order input -> output) as one matrix chain
+    in homogeneous coordinates: Wt_k = [[W_k, b_k],[0, 1]] zero-padded to multiples of 4, prefix products
+    At_k = Wt_k .. Wt_1, suffix products B_3 = Wt_4 Wt_3, B_2 = B_3 Wt_2 (so that every product of the forward and of the
+    backward is at most two dependent launches deep), packed gradients Gt_k = [dW_k | db_k], and the index map through
+    which Adadelta reads the packed gradient and keeps the packed weight current."""
+
+    def __init__(self, ops, fp, k0, dev):
+        self.ops, self.fp = ops, fp
+        f32 = dict(dtype=torch.float32, device=dev)
+        shapes = [fp.shapes[2 * (k0 + k)] for k in range(4)]
+        w = self.widths = [shapes[0][1]] + [sh[0] for sh in shapes]
+        e = self.e = [_round4(v + 1) for v in w]
+        poff = [0]
+        for k in range(1, 5):
+            poff.append(poff[-1] + e[k] * e[k - 1])
+        self.Wt_all, self.Gt_all = torch.zeros(poff[-1], **f32), torch.zeros(poff[-1], **f32)
+        self.Wt = [None] + [self.Wt_all[poff[k - 1]:poff[k]].view(e[k], e[k - 1]) for k in range(1, 5)]
+        self.Gt = [None] + [self.Gt_all[poff[k - 1]:poff[k]].view(e[k], e[k - 1]) for k in range(1, 5)]
+        self.At = [None, self.Wt[1]] + [torch.zeros(e[k], e[0], **f32) for k in range(2, 5)]
+        self.M = [None, self.Gt[1]] + [torch.zeros(e[k], e[0], **f32) for k in range(2, 5)]
+        self.B3, self.B2 = torch.zeros(e[4], e[2], **f32), torch.zeros(e[4], e[1], **f32)
+        first = 2 * k0
+        self.lo = fp.offsets[first]
+        self.hi = fp.offsets[first + 8] if first + 8 < len(fp.offsets) else fp.total
+        pmap = torch.full((self.hi - self.lo,), -1, dtype=torch.int32)
+        for k in range(1, 5):
+            wk, wk1 = w[k], w[k - 1]
+            r = torch.arange(wk, dtype=torch.int32)[:, None] * e[k - 1]
+            ow, ob = fp.offsets[first + 2 * (k - 1)] - self.lo, fp.offsets[first + 2 * (k - 1) + 1] - self.lo
+            pmap[ow:ow + wk * wk1] = (poff[k - 1] + r + torch.arange(wk1, dtype=torch.int32)[None, :]).reshape(-1)
+            pmap[ob:ob + wk] = (poff[k - 1] + r + wk1).reshape(-1)
+        self.pmap = pmap.to(dev)
+        layers = [(fp.view(fp.flat, first + 2 * (k - 1)), fp.view(fp.flat, first + 2 * (k - 1) + 1), self.Wt[k]) for k in range(1, 5)]
+        ops.homogeneous_pack(layers, unpack=False)
+        self.refresh()
+
+    def refresh(self):
+        """Prefix and suffix products of the current packed weights."""
+        Wt, At = self.Wt, self.At
+        self.ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3)])
+        self.ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
+
+    def forward(self, xh, y):
+        """y [rows, w4] = [x|1] . At_4^T  (xh [rows, e0] carries the ones column at index w0)."""
+        self.ops.linear_forward(xh, self.At[4][:self.widths[4]], None, y)
+
+    def input_grad(self, dy, dxh):
+        """dxh [rows, e0] = dy . At_4 (its column w0 is the gradient of the homogeneous coordinate: not a parameter)."""
+        self.ops.linear_backward_input(dy, self.At[4][:dy.shape[1]], dxh)
+
+    def backward(self, dy, xh):
+        """Packed gradients Gt_k from dy [rows, out] (out = w4, or w4 zero-padded to a multiple of 4) and xh [rows, e0]."""
+        ops, M, Gt, At = self.ops, self.M, self.Gt, self.At
+        ops.linear_backward_params(dy, xh, M[4][:dy.shape[1]], None)
+        ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])])
+        ops.gemm_grouped([("NT", M[4], At[3], Gt[4]), ("NT", M[3], At[2], Gt[3]), ("NT", M[2], At[1], Gt[2])])
+
+    def update(self, **adadelta):
+        fp, lo, hi = self.fp, self.lo, self.hi
+        self.ops.adadelta_step_packed(fp.flat[lo:hi], self.pmap, self.Gt_all, self.Wt_all, fp.sq[lo:hi], fp.acc[lo:hi], **adadelta)
+        self.refresh()
 
 
 class KLStepEngine:
@@ -37,22 +105,20 @@ class KLStepEngine:
         f32 = dict(dtype=torch.float32, device=self.dev)
 
         self.gen = [m for m in generator.main if isinstance(m, torch.nn.Linear)]
-        self.enc = [m for m in detector.encoder.main if isinstance(m, torch.nn.Linear)]
-        self.dec = [m for m in detector.decoder.main if isinstance(m, torch.nn.Linear)]
-        assert len(self.gen) == 4 and len(self.enc) == 4 and len(self.dec) == 4
+        enc = [m for m in detector.encoder.main if isinstance(m, torch.nn.Linear)]
+        dec = [m for m in detector.decoder.main if isinstance(m, torch.nn.Linear)]
+        assert len(self.gen) == 4 and len(enc) == 4 and len(dec) == 4
         L = self.L = self.gen[0].in_features
-        self.Lp = _round4(L)
-        det_params = [q for m in self.enc + self.dec for q in (m.weight, m.bias)]
+        det_params = [q for m in enc + dec for q in (m.weight, m.bias)]
         self.fp = FlatParams(det_params, self.dev)          # detector parameters become views of one flat buffer
-        self.W = [self.fp.view(self.fp.flat, 2 * k) for k in range(8)]
-        self.b = [self.fp.view(self.fp.flat, 2 * k + 1) for k in range(8)]
-        # the weight gradients contract over the 2n stacked rows while their outputs are small: the row range is cut into
-        # slabs (partial sums, fixed order) so that a launch fills the chip; Adadelta sums the slabs itself
-        self.splits = max(1, min(8, (2 * n) // 256))
-        self.gslab = torch.zeros(self.splits, self.fp.total, dtype=torch.float32, device=self.dev)
-        self.dW = [self.fp.view(self.gslab[0], 2 * k) for k in range(8)]
-        self.db = [self.fp.view(self.gslab[0], 2 * k + 1) for k in range(8)]
-        self.enc_end = self.fp.offsets[8]                   # flat range [0, enc_end) = encoder, [enc_end, total) = decoder
+        self.E = CollapsedChain(ops, self.fp, 0, self.dev)  # encoder: d -> 8L -> 4L -> 2L -> L
+        self.D = CollapsedChain(ops, self.fp, 4, self.dev)  # decoder: L -> 2L -> 4L -> 8L -> d
+        eE, eD = self.E.e[0], self.D.e[0]                   # padded homogeneous input widths: round4(d + 1), round4(L + 1)
+        # MMD operand: the L encoding columns only.  (Including the ones column would be exact on paper -- a constant column
+        # shifts no distance -- but in fp32 it adds 1 to every squared norm and Gram entry, and L = s_i + s_j - 2 g then
+        # cancels catastrophically against distances of ~1e-6.)
+        self.p = L
+        self.eD = eD
 
         # generator forward (no gradient)
         self.z = torch.zeros(n, L, **f32)
@@ -61,17 +127,16 @@ class KLStepEngine:
         self.U = torch.zeros(n, d, **f32)
         self.perm = torch.zeros(1, n, dtype=torch.int32, device=self.dev)
         self.sqxp = torch.zeros(2 * n, **f32)               # row norms of [batch ; U*batch] (a by-product nobody reads here)
-        # detector on the stacked rows: act[0] = [batch ; U*batch] (pad columns zero), act[4] = enc, act[8] = dec
-        widths = [m.out_features for m in self.enc + self.dec]
-        self.XP = torch.zeros(2 * n, dp, **f32)
-        self.act = [self.XP[:, :d]] + [torch.zeros(2 * n, _round4(w), **f32)[:, :w] for w in widths]
-        self.encZ = self.act[4]                             # [2n, L] view of a [2n, Lp] buffer (pad columns stay zero)
-        self.encZp = self.encZ.as_strided((2 * n, self.Lp), (self.Lp, 1))
-        # gradients of the activations; at the encoder output two contributions meet (MMD and decoder): two slabs
-        self.dact = [None] + [torch.zeros(2 * n, w, **f32) for w in widths]
-        self.msplits = max(1, min(8, (2 * n) // 256))           # split-K slabs of the MMD backward (32 output tiles only)
-        self.denc = torch.zeros(1 + self.msplits, 2 * n, self.Lp, **f32)
-        self.dact[4] = self.denc[0][:, :L]
+        # detector on the 2n stacked rows, homogeneous layouts: XPh = [batch ; U*batch | 1], encH = [enc | 1], dec
+        self.XPh = torch.zeros(2 * n, eE, **f32)
+        self.XPh[:, d] = 1.0
+        self.encH = torch.zeros(2 * n, eD, **f32)
+        self.encH[:, L] = 1.0
+        self.dec = torch.zeros(2 * n, dp, **f32)            # pad columns stay zero
+        self.ddec = torch.zeros(2 * n, dp, **f32)           # gradient of dec (pad columns zero: the vector path of M_4)
+        # at the encoder output the decoder path (slab 0) and the split-K slabs of the MMD backward meet
+        self.msplits = max(1, min(8, (2 * n) // 256))
+        self.denc = torch.zeros(1 + self.msplits, 2 * n, eD, **f32)
         self.mse_part = torch.zeros(2, (n + 3) // 4, dtype=torch.float64, device=self.dev)
         # MMD on the encodings (gradient for all 2n rows)
         self.sq = torch.zeros(2 * n, **f32)
@@ -121,13 +186,14 @@ class KLStepEngine:
         g.replay()
 
     def _forward(self, want_grad):
-        ops, n, d = self.ops, self.n, self.d
+        ops, n, d, L = self.ops, self.n, self.d, self.L
         for k, m in enumerate(self.gen):
             ops.linear_forward(self.gact[k], m.weight.detach(), m.bias.detach(), self.gact[k + 1])
-        ops.mask_project_forward(self.gact[4], self.data, self.perm, self.S, self.U, self.XP[:n], self.XP[n:], self.sqxp[:n], self.sqxp[n:])
-        for k in range(8):
-            ops.linear_forward(self.act[k], self.W[k], self.b[k], self.act[k + 1])
-        Z, p = self.encZp, self.Lp
+        ops.mask_project_forward(self.gact[4], self.data, self.perm, self.S, self.U, self.XPh[:n], self.XPh[n:], self.sqxp[:n],
+                                 self.sqxp[n:])
+        self.E.forward(self.XPh, self.encH[:, :L])
+        self.D.forward(self.encH, self.dec[:, :d])
+        Z, p = self.encH, self.p
         ops.row_sqnorm(Z, self.sq, p)
         if not self.has_bw:  # first call of the (process-wide) RBF calibrates its bandwidth (Mmd_loss_constrained.py:16-20)
             ops.mmd_gram(Z, self.sq, n, p, None, self.tiles0, True, None, 0, self.partial)
@@ -157,30 +223,16 @@ class KLStepEngine:
         gs = -0.1 * 2.0 / (float(n) * d)
         for h in range(2):
             rows = slice(h * n, (h + 1) * n)
-            ops.mse_grad(self.XP[rows, :d], self.act[8][rows], gs, self.mse_part[h], self.dact[8][rows])
+            ops.mse_grad(self.XPh[rows, :d], self.dec[rows, :d], gs, self.mse_part[h], self.ddec[rows, :d])
             ops.sum_f64(self.mse_part[h], (n + 3) // 4, 1.0 / (float(n) * d), self.mse[h:h + 1])
             ops.sum_f64(self.mse_part[h], (n + 3) // 4, 1.0 / (float(n) * d), self.acc_mse[h:h + 1], accumulate=True)
+        adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=-1.0)
+        if train_encoder:  # both read the CURRENT decoder products: before the decoder update
+            self.D.input_grad(self.ddec, self.denc[0])
+            ops.mmd_backward(self.Wg, self.encH, 0, 2 * n, 2 * n, self.p, None, self.denc[1], self.msplits, 2 * n * self.eD)
+        self.D.backward(self.ddec, self.encH)
+        self.D.update(**adadelta)
         if train_encoder:
-            ops.mmd_backward(self.Wg, self.encZp, 0, 2 * n, 2 * n, self.Lp, None, self.denc[1], self.msplits, 2 * n * self.Lp)
-        # decoder: layers 7..4 of the stacked chain
-        g = self.dact[8]
-        for k in (7, 6, 5, 4):
-            ops.linear_backward_params(g, self.act[k], self.dW[k], self.db[k], self.splits, self.fp.total)
-            if k > 4:
-                ops.linear_backward_input(g, self.W[k], self.dact[k])
-                g = self.dact[k]
-            elif train_encoder:
-                ops.linear_backward_input(g, self.W[k], self.denc[0][:, :L])
-        adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=-1.0, nslabs=self.splits,
-                        slab_stride=self.fp.total)
-        lo = self.enc_end
-        ops.adadelta_step(self.fp.flat[lo:], self.gslab[0][lo:], self.fp.sq[lo:], self.fp.acc[lo:], **adadelta)
-        if train_encoder:
-            ops.reduce_slabs(self.denc, 2 * n * self.Lp, 1 + self.msplits, self.denc[0].view(-1))  # d enc = decoder path + MMD slabs
-            g = self.dact[4]
-            for k in (3, 2, 1, 0):
-                ops.linear_backward_params(g, self.act[k], self.dW[k], self.db[k], self.splits, self.fp.total)
-                if k:
-                    ops.linear_backward_input(g, self.W[k], self.dact[k])
-                    g = self.dact[k]
-            ops.adadelta_step(self.fp.flat[:lo], self.gslab[0][:lo], self.fp.sq[:lo], self.fp.acc[:lo], **adadelta)
+            ops.reduce_slabs(self.denc, 2 * n * self.eD, 1 + self.msplits, self.denc[0].view(-1))  # d enc = decoder path + MMD slabs
+            self.E.backward(self.denc[0][:, :L], self.XPh)
+            self.E.update(**adadelta)
