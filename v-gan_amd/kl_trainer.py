@@ -72,9 +72,9 @@ class CollapsedChain:
         """y [rows, w4] = [x|1] . At_4^T  (xh [rows, e0] carries the ones column at index w0)."""
         self.ops.linear_forward(xh, self.At[4][:self.widths[4]], None, y)
 
-    def input_grad(self, dy, dxh):
-        """dxh [rows, e0] = dy . At_4 (its column w0 is the gradient of the homogeneous coordinate: not a parameter)."""
-        self.ops.linear_backward_input(dy, self.At[4][:dy.shape[1]], dxh)
+    def input_grad(self, dy, dx):
+        """dx [rows, w0] = dy . At_4[:, :w0]: the gradient of the chain's real inputs (not of the homogeneous coordinate)."""
+        self.ops.linear_backward_input(dy, self.At[4][:dy.shape[1], :dx.shape[1]], dx)
 
     def backward(self, dy, xh):
         """Packed gradients Gt_k from dy [rows, out] (out = w4, or w4 zero-padded to a multiple of 4) and xh [rows, e0]."""
@@ -137,7 +137,7 @@ class KLStepEngine:
         # at the encoder output the decoder path (slab 0) and the split-K slabs of the MMD backward meet
         self.msplits = max(1, min(8, (2 * n) // 256))
         self.denc = torch.zeros(1 + self.msplits, 2 * n, eD, **f32)
-        self.mse_part = torch.zeros(2, (n + 3) // 4, dtype=torch.float64, device=self.dev)
+        self.mse_part = torch.zeros((2 * n + 3) // 4, dtype=torch.float64, device=self.dev)
         # MMD on the encodings (gradient for all 2n rows)
         self.sq = torch.zeros(2 * n, **f32)
         self.tiles = ops.build_tiles(n, 2, device=self.dev)
@@ -150,9 +150,8 @@ class KLStepEngine:
         self.colpart = torch.zeros(ops.colmax_chunks(n) * d, dtype=torch.int64, device=self.dev)
         self.colkey = torch.zeros(d, dtype=torch.int64, device=self.dev)
         self.mmd = torch.zeros(1, **f32)                    # MMD^2 + penalty of the last step
-        self.mse = torch.zeros(2, **f32)                    # mse(batch, dec_X), mse(U*batch, dec_P) of the last step
-        self.acc_mmd = torch.zeros(1, **f32)                # epoch accumulators (sum over steps)
-        self.acc_mse = torch.zeros(2, **f32)
+        self.acc_mmd = torch.zeros(1, **f32)                # epoch accumulators (sums over steps)
+        self.acc_mse = torch.zeros(1, **f32)                # mse(batch, dec_X) + mse(U*batch, dec_P)
 
     # ---- host-side controls -------------------------------------------------------------------------
     def set_bandwidth(self, value):
@@ -160,8 +159,8 @@ class KLStepEngine:
         self.has_bw = True
 
     def epoch_sums(self):
-        """(sum of MMD terms, sum of mse_X, sum of mse_P) since the last call -- one host sync."""
-        out = (float(self.acc_mmd.item()), float(self.acc_mse[0].item()), float(self.acc_mse[1].item()))
+        """(sum of MMD terms, sum of mse_X + mse_P) since the last call -- one host sync."""
+        out = (float(self.acc_mmd.item()), float(self.acc_mse.item()))
         self.acc_mmd.zero_()
         self.acc_mse.zero_()
         return out
@@ -221,18 +220,16 @@ class KLStepEngine:
         self._forward(want_grad=train_encoder)
         # gradients of G = MMD - 0.1 mse_X - 0.1 mse_P  (= -loss_D)
         gs = -0.1 * 2.0 / (float(n) * d)
-        for h in range(2):
-            rows = slice(h * n, (h + 1) * n)
-            ops.mse_grad(self.XPh[rows, :d], self.dec[rows, :d], gs, self.mse_part[h], self.ddec[rows, :d])
-            ops.sum_f64(self.mse_part[h], (n + 3) // 4, 1.0 / (float(n) * d), self.mse[h:h + 1])
-            ops.sum_f64(self.mse_part[h], (n + 3) // 4, 1.0 / (float(n) * d), self.acc_mse[h:h + 1], accumulate=True)
+        # both squared-error terms have the same weight and the same 1/(n d): one pass over the 2n stacked rows, one fold
+        ops.mse_grad(self.XPh[:, :d], self.dec[:, :d], gs, self.mse_part, self.ddec[:, :d])
+        ops.sum_f64(self.mse_part, self.mse_part.numel(), 1.0 / (float(n) * d), self.acc_mse, accumulate=True)
         adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=-1.0)
         if train_encoder:  # both read the CURRENT decoder products: before the decoder update
-            self.D.input_grad(self.ddec, self.denc[0])
+            self.D.input_grad(self.ddec, self.denc[0][:, :L])  # columns >= L of every slab stay zero
             ops.mmd_backward(self.Wg, self.encH, 0, 2 * n, 2 * n, self.p, None, self.denc[1], self.msplits, 2 * n * self.eD)
         self.D.backward(self.ddec, self.encH)
         self.D.update(**adadelta)
         if train_encoder:
             ops.reduce_slabs(self.denc, 2 * n * self.eD, 1 + self.msplits, self.denc[0].view(-1))  # d enc = decoder path + MMD slabs
-            self.E.backward(self.denc[0][:, :L], self.XPh)
+            self.E.backward(self.denc[0][:, :_round4(L)], self.XPh)  # zero pad columns: the vector path of M_4
             self.E.update(**adadelta)

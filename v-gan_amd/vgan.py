@@ -420,9 +420,9 @@ class VGAN(_RunFolder):
                     for p in detector.decoder.parameters():  # src/vgan.py:257-258
                         p.requires_grad = True
                     engine.detector_step(idx, noise_tensor.normal_(), train_encoder=encoder_trainable)
-                mmd_sum, mse_x, mse_p = engine.epoch_sums()
+                mmd_sum, mse_sum = engine.epoch_sums()
                 # batch_loss_D = -(MMD - .1 mse(batch, batch_dec) - .1 mse(projected, projected_dec)), src/vgan.py:275-277
-                detector_loss = -(mmd_sum - 0.1 * mse_x - 0.1 * mse_p) / batch_number
+                detector_loss = -(mmd_sum - 0.1 * mse_sum) / batch_number
                 sync_bandwidth()
                 iternum_d += 1
                 iternum_g = 1
