@@ -888,3 +888,25 @@ def test_mask_project_forward_bf3_equals_two_launches(ops, n, d):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert float(a["Z"][:n, :d].abs().sum()) > 0 and int((a["ZTh"] != 0).sum()) > 0
+
+
+def test_integration_stub_from_this_file():
+    """The ctypes binding printed in INTEGRATION.md (section 2) is executed as written and checked against the oracle."""
+    import re
+    from conftest import REPO
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def mmd2" in b]
+    assert len(block) == 1
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(REPO)  # the stub opens the library by its path relative to the repository root
+    try:
+        exec(block[0], ns)
+    finally:
+        os.chdir(cwd)
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(200, 24)).astype(np.float32)
+    Y = (X * rng.uniform(0.3, 1.0, size=X.shape)).astype(np.float32)
+    loss, bw = ns["mmd2"](dev(X), dev(Y))
+    want = orc.mmd_forward(X.astype(np.float64), Y.astype(np.float64), np.ones_like(X, dtype=np.float64), 0.0)
+    assert abs(float(loss) - float(want["mmd2"])) < 1e-5 and abs(float(bw) / float(want["bw"]) - 1) < 1e-5
