@@ -463,7 +463,8 @@ struct GemmTile {
 // NW waves per workgroup (4 or 16): the K loop of these products is bound by the 64-cycle fp32 MFMAs each wave issues
 // back to back (BK = 128, NW = 4: 16 per wave and K tile = 0.43 us), so for long contractions 16 waves (one k-group each)
 // shorten it (measured: M_4 product 10.0 -> 8.9 us, the K = 788 group 10.0 -> 8.2 us; keeping four K tiles of loads in
-// flight on top of that was slower again, 9.9 / 9.6 us); wave w then owns result registers [w*16/NW, (w+1)*16/NW).
+// flight on top of that was slower again, 9.9 / 9.6 us, and so was a 256-deep K tile for the 16-wave variant, 9.2 / 7.2 us);
+// wave w then owns result registers [w*16/NW, (w+1)*16/NW).
 template <int BK, int LA, int LB, int VEC, int NW = 4>
 struct GemmTileKS {
     static constexpr int T = 32;
