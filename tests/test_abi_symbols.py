@@ -52,3 +52,21 @@ def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# ", ""), f"{f} mentions the oracle"
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point validates its arguments before it touches the device: bad calls return VGAN_ERR_ARG (1) and leave
+    a message in vgan_last_error(), with or without a GPU."""
+    import vgan_amd
+    lib = vgan_amd.lib.load()
+    null = None
+    assert lib.vgan_linear_forward(null, 0, 1, 0, null, 0, null, null, 0, 0, 0, 0, null) != 0
+    assert b"bad argument" in lib.vgan_last_error()
+    assert lib.vgan_mmd_gram(null, 0, null, 0, 0, null, null, 0, 0, null, 0, 0, null, null) != 0
+    assert lib.vgan_mmd_gram_bf3(null, null, 0, null, 0, null, null, 0, 64, null, null, 0, 0, null, null, 0, 0, 0, null, 0, 0, null) != 0
+    assert lib.vgan_mask_project_forward_bf3(null, 0, null, 0, null, null, 1, 0, null, null, 0, null, null, null, 0, null, null, 0, 0, 0,
+                                             null) != 0
+    assert lib.vgan_gemm_grouped(null, 0, null) != 0
+    assert lib.vgan_adadelta_step(null, null, 1, 0, null, null, 0, 0.1, 0.9, 1e-6, 0.0, 1.0, null) != 0
+    assert lib.vgan_rbf_kernel_matrix(null, 0, 0, 0, null, 1.0, null, 0, null) != 0
+    assert b"twosample.hip" in lib.vgan_last_error()
