@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                                                                  int ldz, float* __restrict__ sq, unsigned short* __restrict__ Zh,
                                                                  unsigned short* __restrict__ Zl, int kp, unsigned short* __restrict__ ZTh,
                                                                  unsigned short* __restrict__ ZTl, int kn, int n, int d) {
-    constexpr int R = 8;                                  // rows per workgroup = waves per workgroup (512 threads)
+    constexpr int R = 8;  // rows per workgroup = waves per workgroup (512 threads; 4 rows in 256 threads measured the same: 11.7 us)
     extern __shared__ __attribute__((aligned(16))) unsigned short tile[];  // [4 images: Xh, Xl, Yh, Yl][R][ldt]
     const int ldt = 4 * (d >> 2) + 8;                     // bf16 elements per tile row (8-byte stores stay aligned)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
