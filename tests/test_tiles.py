@@ -83,3 +83,33 @@ def test_bad_arguments():
     assert l.vgan_mmd_build_tiles(64, 2, 0, 2, 64, None, 0) == -1
     assert b"grad_mode 2" in l.vgan_last_error()
     assert l.vgan_mmd_build_tiles(64, 1, 0, 1, 96, None, 0) == -1  # only 64 and 128 exist
+
+
+def test_tables_property_random_shapes():
+    """Property test over random (n, world, tile, mode): the union of the rank tables covers every needed pair exactly once,
+    every Wg entry that the mode asks for is written exactly once, and no tile leaves its block."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(n=st.integers(1, 700), world=st.sampled_from([1, 1, 2, 3, 4, 8]), tile=st.sampled_from([64, 128]),
+           mode=st.sampled_from([0, 1, 2]))
+    def check(n, world, tile, mode):
+        if world > 1 and (mode == 2 or n < world):
+            return
+        if world > 1:
+            mode = 1
+        tabs = [table(n, mode, r, world, tile) for r in range(world)]
+        seen, writes, slot_ok = coverage(n, tabs, None, [0] * world, tile)
+        assert slot_ok
+        N = 2 * n
+        want = np.ones((N, N))
+        want[:n, n:] = 0
+        assert np.array_equal(seen, want)
+        if mode == 0:
+            assert writes.sum() == 0
+        elif mode == 1:
+            assert np.array_equal(writes[n:], np.ones((n, N))) and writes[:n].sum() == 0
+        else:
+            assert np.array_equal(writes, np.ones((N, N)))
+
+    check()
