@@ -115,15 +115,17 @@ def kernel_rooflines(eng):
     tiles64 = eng.tiles if eng.gram_tile == 64 else ops.build_tiles(n, 1, eng.rank, eng.world, device=eng.Z.device)
     part64 = torch.zeros(tiles64.shape[0], 4, device=eng.Z.device)
     add("mmd_gram_kernel<4,false,1>", time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, tiles64, False, Wg, n + lo, part64)))
-    add("mmd_backward_kernel<4,2>", time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU)))
+    add("mmd_backward_kernel<4,2>", time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU,
+                                                                             mul_shift=eng.center)))
     if eng.bf3:
         gs = nl * eng.dp
         gname = "mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"
         add(gname, time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles, eng.Wh, eng.Wl, n + lo, eng.partial,
                                                         tile=eng.gram_tile)))
-        big_bwd = ((d + 127) // 128) * ((nl + 127) // 128) * eng.bsplits >= 512 or os.environ.get("VGAN_BWD_TILE") == "128"  # library's rule
+        big_bwd = ops.mmd_backward_bf3_tile(nl, d, eng.bsplits, eng.bwd_tile) == 128  # the library's own choice
         add("mmd_backward_bf3_big_kernel" if big_bwd else "mmd_backward_bf3_kernel<64>", time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d,
-                                                                                 eng.Z[lo:lo + nl], eng.gU, eng.bsplits, gs)))
+                                                                                 eng.Z[lo:lo + nl], eng.gU, eng.bsplits, gs,
+                                                                                 mul_shift=eng.center, tile=eng.bwd_tile)))
         out["bf3_prepare_kernel"] = {"ms": time_kernel(lambda: ops.mmd_bf3_prepare(eng.Z, 2 * n, d, eng.Zh, eng.Zl, eng.ZTh, eng.ZTl))}
     return out
 
@@ -248,8 +250,7 @@ def main():
 
     torch.manual_seed(1234)
     use_graph = not args.no_graph and backend == "nccl"
-    ekw = {"mmd_precision": args.precision} if args.precision else {}
-    eng, data, params = build_engine(rank, world, use_graph, **ekw)
+
     def prewarm(e):
         # every rank must run the SAME number of steps (each one holds a collective and draws the shared shuffles): rank 0
         # times one epoch and broadcasts how many more to run
@@ -263,70 +264,69 @@ def main():
             run_steps(e, EPOCH_BATCHES, (it + 1) * EPOCH_BATCHES)
         torch.cuda.synchronize()
 
-    try:
-        prewarm(eng)
-        run_steps(eng, args.warmup, 0)
+    def timed_leg(**ekw):
+        """Build an engine, pre-warm, W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize on both
+        sides; max over ranks.  Returns (engine, seconds, graph used, mean loss of the timed steps)."""
+        nonlocal use_graph
+        eng, data, params = build_engine(rank, world, use_graph, **ekw)
+        try:
+            prewarm(eng)
+            run_steps(eng, args.warmup, 0)
+            torch.cuda.synchronize()
+        except Exception as e:  # a collective that cannot be captured: fall back to eager launches (same process)
+            if not use_graph:
+                raise
+            print(f"[bench] HIP-graph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            use_graph = False
+            eng, data, params = build_engine(rank, world, False, **ekw)
+            prewarm(eng)
+            run_steps(eng, args.warmup, 0)
+            torch.cuda.synchronize()
+        eng.epoch_loss()
+        if dist:
+            dist.barrier()
         torch.cuda.synchronize()
-    except Exception as e:  # a collective that cannot be captured: fall back to eager launches
-        if not use_graph:
-            raise
-        print(f"[bench] HIP-graph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
-        use_graph = False
-        eng, data, params = build_engine(rank, world, False, **ekw)
-        prewarm(eng)
-        run_steps(eng, args.warmup, 0)
+        t0 = time.perf_counter()
+        run_steps(eng, args.steps, args.warmup)
         torch.cuda.synchronize()
-    eng.epoch_loss()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        mean_loss = eng.epoch_loss() * EPOCH_BATCHES / max(args.steps, 1)
+        return eng, data, params, elapsed, mean_loss
 
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(eng, args.steps, args.warmup)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    mean_loss = eng.epoch_loss() * EPOCH_BATCHES / max(args.steps, 1)
-
+    ekw = {"mmd_precision": args.precision} if args.precision else {}
+    eng, data, params, elapsed, mean_loss = timed_leg(**ekw)
     kern = kernel_rooflines(eng)
-    if rank == 0:
-        steps_per_s = args.steps / elapsed
-        out = {
-            "metric": f"V-GAN train steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": steps_per_s, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (MMD products: split-bf16 x3 on the bf16 MFMA, fp32 accumulate)" if eng.bf3 else "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "global_batch": N_BATCH, "features": D_FEAT, "latent": eng.L,
-                       "rows_per_gpu": eng.nl, "parallelism": f"dp{world} (row-sharded Gram, replicated generator)",
-                       "hip_graph": bool(use_graph), "mean_loss": mean_loss, "prewarm_s": args.prewarm_seconds,
-                       "generator": eng.mode, "mmd_precision": eng.precision, "gram_tile": eng.gram_tile},
-        }
-        def traffic_of(kernel):
-            tp = os.path.join(ROOT, "profiles", "traffic.json")
-            if not (os.path.exists(tp) and world == 1):
-                return None
-            try:
-                return json.load(open(tp)).get(kernel, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                return None
+    step_flop = 8.0 * N_BATCH * N_BATCH * D_FEAT + 6.0 * N_BATCH * eng.fp.total
 
-        step_flop = 8.0 * N_BATCH * N_BATCH * D_FEAT + 6.0 * N_BATCH * eng.fp.total
-        if eng.bf3:
+    def traffic_of(kernel):
+        """HBM-side bytes per launch of `kernel` from the COMMITTED PMC pass (profiles/traffic.json, regenerated by
+        `python tools/pmc_traffic.py` under rocprofv3 --pmc: counters cannot be collected inside this timing run)."""
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if not (os.path.exists(tp) and world == 1 and CONFIG == "c3"):
+            return None
+        try:
+            return json.load(open(tp)).get(kernel, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+
+    def roofline_of(e, kern, steps_per_s):
+        if e.bf3:
             # The dominant kernel issues v_mfma_f32_32x32x16_bf16; `achieved` is ALGORITHMIC flops / launch time as the
             # contract says, `peak` the dense bf16 MFMA rate.  Each algorithmic product costs three bf16 products
             # (hi.hi' + hi.lo' + lo.hi'), so the executed MFMA rate is 3x `achieved`; both fractions are reported.
-            name, peak = ("mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"), BF16_MFMA_PEAK_TFLOPS
+            name, peak = ("mmd_gram_bf3_big_kernel" if e.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"), BF16_MFMA_PEAK_TFLOPS
             g = kern[name]
             extra = {"executed_mfma_tflops": 3.0 * g["tflops"], "executed_frac": 3.0 * g["tflops"] / peak,
                      "vs_fp32_mfma_peak": g["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                     "note": "fp32-accurate Gram on the bf16 MFMA via a 3-way operand split; the fp32-MFMA kernel of the same "
-                             "contraction is listed under 'also' with its own peak (157.3)"}
+                     "note": "fp32-accurate Gram on the bf16 MFMA via a 3-way operand split; the fp32-MFMA kernels of the same "
+                             "contraction are timed as a whole step in 'fp32_mode'"}
         else:
             name, peak = "mmd_gram_kernel<4,false,1>", FP32_MFMA_PEAK_TFLOPS
             g = kern[name]
@@ -339,16 +339,52 @@ def main():
             also[k] = {"achieved": v["tflops"], "peak": pk, "frac": v["tflops"] / pk, "avg_launch_ms": v["ms"]}
         if "bf3_prepare_kernel" in kern:
             also["bf3_prepare_kernel"] = {"avg_launch_ms": kern["bf3_prepare_kernel"]["ms"], "bound": "hbm"}
-        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
-                           "frac": g["tflops"] / peak, "traffic": traffic_of(name.split("<")[0]), "avg_launch_ms": g["ms"],
-                           "algorithmic_flop_per_launch": g["flop"], **extra, "also": also,
-                           "step_tflops": step_flop * steps_per_s / world / 1e12,
-                           "step_frac_of_fp32_mfma_peak": step_flop * steps_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+        tr = traffic_of(name.split("<")[0])
+        return {"bound": "mfma", "kernel": name, "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
+                "frac": g["tflops"] / peak, "traffic": tr,
+                "traffic_source": ("profiles/traffic.json: committed rocprofv3 --pmc pass (tools/pmc_traffic.py), not measured "
+                                   "in this run") if tr is not None else None,
+                "avg_launch_ms": g["ms"], "algorithmic_flop_per_launch": g["flop"], **extra, "also": also,
+                "step_tflops": step_flop * steps_per_s / world / 1e12,
+                "step_frac_of_fp32_mfma_peak": step_flop * steps_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+
+    # The reference's own arithmetic is fp32 end to end.  When the engine's choice is the split-bf16 mode, the SAME
+    # workload is timed a second time with the fp32-MFMA kernels (same warm-up discipline, same step count), so that the
+    # driver's line carries a step rate for both arithmetic modes.
+    fp32_block = None
+    if eng.bf3:
+        e32, _, _, el32, ml32 = timed_leg(mmd_precision="fp32")
+        k32 = kernel_rooflines(e32)
+        fp32_block = {"value": args.steps / el32, "unit": "steps/s", "ms_per_step": 1e3 * el32 / args.steps, "steps": args.steps,
+                      "warmup": args.warmup, "mmd_precision": "fp32", "mean_loss": ml32, "dtype": "f32 (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
+                      "roofline": roofline_of(e32, k32, args.steps / el32)}
+        del e32
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        steps_per_s = args.steps / elapsed
+        out = {
+            "metric": f"V-GAN train steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": steps_per_s, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": ("f32; MMD contractions of `value`: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (centred operand); "
+                      "the same step with the fp32 MFMA is timed in `fp32_mode`") if eng.bf3 else "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD, "global_batch": N_BATCH, "features": D_FEAT, "latent": eng.L,
+                       "rows_per_gpu": eng.nl, "parallelism": f"dp{world} (row-sharded Gram, replicated generator)",
+                       "hip_graph": bool(use_graph), "mean_loss": mean_loss, "prewarm_s": args.prewarm_seconds,
+                       "generator": eng.mode, "mmd_precision": eng.precision, "gram_tile": eng.gram_tile},
+        }
+        out["roofline"] = roofline_of(eng, kern, steps_per_s)
+        if fp32_block is not None:
+            out["fp32_mode"] = fp32_block
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_loss, (X, z) = cpu_baseline(data, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
             gl = gpu_first_loss(params, X, z, mmd_precision=eng.precision)
             out["parity"] = {"mmd_precision": eng.precision, "loss_gpu": gl, "loss_cpu_port": cpu_loss, "abs_diff": abs(gl - cpu_loss), "bar": 1e-4}
+            if eng.bf3:
+                g32 = gpu_first_loss(params, X, z, mmd_precision="fp32")
+                out["parity"]["fp32_mode"] = {"loss_gpu": g32, "abs_diff": abs(g32 - cpu_loss)}
             out["speedup_vs_cpu"] = steps_per_s / cb["value"]
         print(json.dumps(out), flush=True)
     if dist:

@@ -27,7 +27,7 @@ extern "C" {
 #define VGAN_ERR_ARG 1  /* bad shape / null pointer / unsupported configuration */
 #define VGAN_ERR_HIP 2  /* a HIP runtime call or launch failed */
 
-#define VGAN_ABI_VERSION 2
+#define VGAN_ABI_VERSION 3
 
 typedef void* vgan_stream_t; /* hipStream_t */
 
@@ -70,11 +70,20 @@ int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nslabs, float* 
  *   X_batch row i = data[ rows[(t % row_batches) * row_stride + row_offset + i] ], where `rows` is a
  *   whole epoch's table of shuffled indices and t = *row_cursor is the device-side step counter
  *   (row_cursor == NULL: t = 0;  rows == NULL: X_batch row i = data[row_offset + i]).  U may be NULL.
+ *   center (may be NULL): a per-feature constant c[d] subtracted from EVERY row of Z, i.e. Zx[i] = X[i] - c and
+ *   Zy[i] = fl(U[i] * X[i]) - c.  cdist(Z,Z)**2 (Mmd_loss_constrained.py:25) is translation invariant, so the loss and
+ *   its gradient are unchanged in exact arithmetic, while a common offset of a feature no longer eats the mantissa of
+ *   the fp32 (and above all the split-bf16) operands; the step engine passes the data-set mean (vgan_col_mean).
+ *   norm_split != 0: sqx/sqy are the norms of the split values hi + lo that vgan_mmd_bf3_prepare will produce from
+ *   Zx/Zy (what vgan_mmd_gram_bf3 needs: L = s_i + s_j - 2 g is then |zhat_i - zhat_j|^2 exactly).
  * ------------------------------------------------------------------------------------------- */
 int vgan_mask_project_forward(const float* logits, int ldl, const float* data, int ldd,
                               const int32_t* rows, const uint64_t* row_cursor, int row_batches,
                               int row_stride, int row_offset, float* S, float* U, float* Zx, float* Zy,
-                              int ldz, float* sqx, float* sqy, int n, int d, vgan_stream_t stream);
+                              int ldz, float* sqx, float* sqy, int n, int d, const float* center,
+                              int norm_split, vgan_stream_t stream);
+/* out[j] = mean over the rows of data[:, j] (float64 accumulation, fixed order): the `center` of the calls above. */
+int vgan_col_mean(const float* data, int ldd, int rows, int d, float* out, vgan_stream_t stream);
 /* out[i, :d] = data[rows[i], :d], sq[i] = |out[i]|^2 (sq may be NULL): batch rows a rank needs as
  * Gram columns but holds no mask for (data-parallel runs keep the data set replicated). */
 int vgan_gather_rows(const float* data, int ldd, const int32_t* rows, const uint64_t* row_cursor,
@@ -184,10 +193,13 @@ typedef struct vgan_finalize_job {
  * product rule: gU = dY * X).  Z is [ncols, p], Wg is [nr, ncols].
  * splits > 1: the contraction over the Z rows is cut into `splits` slices and slice s writes its
  * PARTIAL result to out + s*slab_stride (the result is linear in the slice sums); the consumer adds
- * the slabs (vgan_mask_backward does, or vgan_reduce_slabs). */
+ * the slabs (vgan_mask_backward does, or vgan_reduce_slabs).
+ * mul_shift (may be NULL; needs mul): per-column constant added to mul, for callers whose Z (and with it the X rows
+ * passed as `mul`) is stored centred: mul + mul_shift is then the batch itself.  Z may be centred freely: the
+ * expression rowsum(Wg_i) z_i - Wg_i . Z = sum_j Wg_ij (z_i - z_j) is translation invariant. */
 int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr,
-                      int ncols, int p, const float* mul, int ldmul, float* out, int ldo,
-                      int splits, int64_t slab_stride, const vgan_finalize_job* finalize,
+                      int ncols, int p, const float* mul, int ldmul, const float* mul_shift, float* out,
+                      int ldo, int splits, int64_t slab_stride, const vgan_finalize_job* finalize,
                       vgan_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * Split-bf16 ("bf16x3") variants of the two dense contractions, for large problems (opt-in precision
@@ -209,11 +221,15 @@ int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const floa
                       uint64_t* colpart, int nrows, int d, vgan_stream_t stream);
 /* vgan_mmd_backward on the split operands: out = 2 (rowsum(W) z - W . Z) * mul with W = Wh + Wl [nr, kn]
  * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue.  splits / slab_stride as in
- * vgan_mmd_backward (slabs of out, summed by the consumer in slab order). */
+ * vgan_mmd_backward (slabs of out, summed by the consumer in slab order); mul_shift as there.
+ * tile: 0 = chosen by the library (128-wide tiles once they fill the chip twice over), or 64 / 128 to force one. */
+/* host-side query (no launch): the tile edge (64 or 128) vgan_mmd_backward_bf3 uses for this shape and `tile` argument */
+int vgan_mmd_backward_bf3_tile(int nr, int p, int splits, int tile);
 int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh,
                           const uint16_t* ZTl, int kn, int kp, const float* Z, int ldz, int wrow0, int nr,
-                          int p, const float* mul, int ldmul, float* out, int ldo, int splits,
-                          int64_t slab_stride, const vgan_finalize_job* finalize, vgan_stream_t stream);
+                          int p, const float* mul, int ldmul, const float* mul_shift, float* out, int ldo,
+                          int splits, int64_t slab_stride, int tile, const vgan_finalize_job* finalize,
+                          vgan_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * Grouped small products: up to VGAN_GEMM_MAX_GROUP independent row-major GEMMs in one launch.
  * Generator_big (src/models/Generator.py:61-66) has no activation between its Linear layers, so its
@@ -236,11 +252,12 @@ int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_
 /* vgan_mask_project_forward fused with vgan_mmd_bf3_prepare for the training step: from logits [n, d] and the
  * batch rows it writes S [n, d], Z = [X ; U*X] ([2n, ldz] fp32), sq [2n] and the split images Zh, Zl [2n, kp],
  * ZTh, ZTl [kp, kn] of Z (pad regions are not touched: pre-zeroed by the caller).  Shape contract: d % 4 == 0,
- * d <= 1024, n % 8 == 0, leading dimensions % 4 == 0, 16-byte aligned bases; otherwise use the two calls. */
+ * d <= 1024, n % 8 == 0, leading dimensions % 4 == 0, 16-byte aligned bases; otherwise use the two calls
+ * (with norm_split = 1).  center as in vgan_mask_project_forward; sq holds the norms of the split values. */
 int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                   const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z,
                                   int ldz, float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,
-                                  uint16_t* ZTl, int kn, int n, int d, vgan_stream_t stream);
+                                  uint16_t* ZTl, int kn, int n, int d, const float* center, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

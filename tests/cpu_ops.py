@@ -81,8 +81,11 @@ class CpuOps:
         flat = rows.reshape(-1).numpy()
         return flat[b * row_stride + row_offset: b * row_stride + row_offset + n].astype(np.int64)
 
+    def col_mean(self, data, out):
+        out[:data.shape[1]].copy_(torch.as_tensor(_np(data).astype(np.float64).mean(0)))
+
     def mask_project_forward(self, logits, data, rows, S, U, Zx, Zy, sqx, sqy, row_cursor=None, row_batches=1, row_stride=0,
-                             row_offset=0):
+                             row_offset=0, center=None, norm_split=False):
         n, d = logits.shape
         u, s = orc.upper_softmax_forward(_np(logits).astype(np.float32))
         S.copy_(torch.as_tensor(s))
@@ -90,16 +93,25 @@ class CpuOps:
             U.copy_(torch.as_tensor(u))
         X = _np(data)[self._rows(rows, row_cursor, row_batches, row_stride, row_offset, n)]
         Y = u * X
+        if center is not None:  # the MMD operand is centred: Z = [X - c ; U*X - c]
+            X, Y = X - _np(center)[:d], Y - _np(center)[:d]
         if Zx is not None:
             Zx[:, :d].copy_(torch.as_tensor(X))
         Zy[:, :d].copy_(torch.as_tensor(Y))
+        if norm_split:  # norms of the bf16 hi + lo values
+            def rounded(a):
+                hi, lo = self._split(a)
+                return (hi.float() + lo.float()).numpy()
+            X, Y = rounded(X), rounded(Y)
         if sqx is not None:
             sqx.copy_(torch.as_tensor((X.astype(np.float64) ** 2).sum(1)))
         sqy.copy_(torch.as_tensor((Y.astype(np.float64) ** 2).sum(1)))
 
-    def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0):
+    def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
+                                 center=None):
         n, d = logits.shape
-        self.mask_project_forward(logits, data, rows, S, None, Z[:n], Z[n:], sq[:n], sq[n:], row_cursor, row_batches, row_stride)
+        self.mask_project_forward(logits, data, rows, S, None, Z[:n], Z[n:], sq[:n], sq[n:], row_cursor, row_batches, row_stride,
+                                  center=center, norm_split=True)
         self.mmd_bf3_prepare(Z, 2 * n, d, Zh, Zl, ZTh, ZTl)
 
     @staticmethod
@@ -224,7 +236,7 @@ class CpuOps:
         if step_counter is not None:
             step_counter += 1
 
-    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0, finalize=None):
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None):
         if finalize is not None:
             self.mmd_finalize(*finalize[0], **finalize[1])
         kchunk = ((ncols + splits - 1) // splits + 31) // 32 * 32
@@ -234,7 +246,7 @@ class CpuOps:
             z = _np(Z)[:ncols, :p].astype(np.float64)
             r = 2.0 * (w.sum(1, keepdims=True) * z[wrow0:wrow0 + nr] - w @ z[lo:hi])
             if mul is not None:
-                r = r * _np(mul)[:nr, :p]
+                r = r * (_np(mul)[:nr, :p] + (_np(mul_shift)[:p] if mul_shift is not None else 0.0))
             o = torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + sl * slab_stride)
             o[:nr, :p].copy_(torch.as_tensor(r))
 
@@ -288,7 +300,8 @@ class CpuOps:
         if S is not None:
             self.colmax_partial(S, row_offset, colpart, from_softmax)
 
-    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None):
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
+                         tile=0):
         if finalize is not None:
             self.mmd_finalize(*finalize[0], **finalize[1])
         for q in range(1, splits):  # the whole product goes to slab 0
@@ -298,8 +311,11 @@ class CpuOps:
         z = _np(Z)[wrow0:wrow0 + nr, :p].astype(np.float64)
         r = 2.0 * ((wh + wl).sum(1, keepdims=True) * z - prod)
         if mul is not None:
-            r = r * _np(mul)[:nr, :p]
+            r = r * (_np(mul)[:nr, :p] + (_np(mul_shift)[:p] if mul_shift is not None else 0.0))
         out[:nr, :p].copy_(torch.as_tensor(r))
+
+    def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
+        return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 
     def gemm_grouped(self, problems):
         outs = []

@@ -604,6 +604,79 @@ def test_finalize_job_riding_in_backward_equals_standalone_finalize(ops, bf3):
     assert int(a["counter"]) == 42 and float(a["loss"]) != 0.0
 
 
+# ---- adversarial operands for the two precision modes ---------------------------------------------
+def adversarial_case(name, n, d, rows, seed=0):
+    """Unstandardised inputs that a 16-bit-operand Gram must survive.  Returns (data, generator params)."""
+    rng = np.random.default_rng(seed + 7)
+    params = orc.synthetic_generator_params(d, seed=3)
+    base = rng.normal(size=(rows, d))
+    if name == "offset10":        # every feature mu/sigma = 10
+        data = base + 10.0
+    elif name == "offset100":     # mu/sigma = 100
+        data = base + 100.0
+    elif name == "scales":        # unstandardised feature scales over six decades, offsets of a few sigma
+        sc = 10.0 ** rng.uniform(-3, 3, size=(1, d))
+        data = (base + rng.uniform(-3, 3, size=(1, d))) * sc
+    elif name in ("neardup", "neardup_offset100"):
+        # Y ~ X: a generator whose last layer is damped (logits vary by ~1e-3 over the batch: far above fp32 resolution, far
+        # below the 5/d margin of the 1/d threshold) and whose bias masks only 5 features, so U = 1 elsewhere, the XY and YY
+        # blocks nearly repeat XX and the bandwidth stays near the sigma^2 scale while (second variant) every row carries a
+        # common offset of 100 sigma -- the worst case for an uncentred operand
+        data = base + (100.0 if name.endswith("100") else 0.0)
+        params[6] = params[6] * np.float32(5e-3)
+        b4 = np.zeros(d, np.float32)
+        b4[rng.choice(d, size=5, replace=False)] = -6.0
+        params[7] = b4
+    else:
+        raise ValueError(name)
+    return np.ascontiguousarray(data, dtype=np.float32), params
+
+
+def oracle_step_with_decisions(params, data, z, weight, snapped, max_ties=8):
+    """oracle.step_forward_backward in float64 with the `s >= 1/d` decisions of upper_softmax (Generator.py:19-21) taken from
+    `snapped` (the GPU's).  With ~8e5 softmax values per batch a handful sit within fp32 rounding of the threshold, where any
+    two fp32 implementations (the reference's included) may decide differently; such ties are accepted only if the float64
+    value is within 1e-5 relative of 1/d, and at most `max_ties` of them."""
+    p64 = [p.astype(np.float64) for p in params]
+    X, z = data.astype(np.float64), z.astype(np.float64)
+    logits, acts = orc.generator_forward(p64, z)
+    s = orc.softmax_rows(logits)
+    d = s.shape[1]
+    ties = snapped != (s >= 1.0 / d)
+    assert ties.sum() <= max_ties and (np.abs(s[ties] * d - 1.0) < 1e-5).all(), f"{int(ties.sum())} decisions differ beyond rounding"
+    U = np.where(snapped, 1.0, s)
+    f = orc.mmd_forward(X, U * X, U, weight)
+    dY, dUp = orc.mmd_backward(X, U * X, U, weight, f["bw"])
+    gs = np.where(snapped, 0.0, dY * X + dUp)
+    dlogits = s * (gs - (gs * s).sum(axis=1, keepdims=True))
+    return dict(loss=f["loss"], bw=f["bw"], grads=orc.generator_backward(p64, acts, dlogits), ties=int(ties.sum()))
+
+
+ADVERSARIAL = ["offset10", "offset100", "scales", "neardup", "neardup_offset100"]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", ADVERSARIAL)
+def test_adversarial_operands_whole_step_vs_fp64(ops, case, precision):
+    """One whole training step at the metric's size (n=1024, d=784) on inputs with large per-feature offsets, scales
+    spanning six decades and near-duplicate [X ; Y] halves, in BOTH precision modes, against the float64 oracle: loss within
+    the 1e-4 bar, bandwidth to 1e-5, every parameter gradient within 1e-3 of its largest entry.  What makes this hold is
+    the centred operand (trainer.NoKLStepEngine.center) and row norms taken from the split values."""
+    n, d = 1024, 784
+    data, params = adversarial_case(case, n, d, rows=n)
+    z = np.random.default_rng(5).normal(size=(n, orc.latent_size(d))).astype(np.float32)
+    eng, _ = make_engine(ops, params, data, n, mmd_precision=precision)
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    eng.set_noise(torch.as_tensor(z))
+    eng.step()
+    want = oracle_step_with_decisions(params, data, z, 10.0, host(eng.S) >= np.float32(1.0 / d))
+    assert abs(float(eng.loss) - float(want["loss"])) < 1e-4, (float(eng.loss), float(want["loss"]))
+    np.testing.assert_allclose(float(eng.bw), float(want["bw"]), rtol=1e-5)
+    for i in range(8):
+        ref = want["grads"][i]
+        np.testing.assert_allclose(host(eng.grad_view(i)), ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-12), err_msg=f"param {i}")
+
+
 # ---- BASELINE.json configs[3] / configs[4] at their full single-GPU sizes -------------------------------------------
 def _dy_rows_fp64(Z, n, bw, rows):
     """Rows of dLoss/dY in float64 from the closed form: dY_i = (4/n^2) [sum_{j in Y} K'_ij (y_i - y_j)
@@ -860,13 +933,19 @@ def test_kl_step_engine_hip_vs_cpu_provider(ops, n, d):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("centred", [False, True])
 @pytest.mark.parametrize("n,d", [(1024, 784), (264, 1024), (72, 20), (128, 100)])
-def test_mask_project_forward_bf3_equals_two_launches(ops, n, d):
+def test_mask_project_forward_bf3_equals_two_launches(ops, n, d, centred):
     """vgan_mask_project_forward_bf3 (mask/projection fused with the bf16x3 operand preparation) is bit-identical to
-    vgan_mask_project_forward followed by vgan_mmd_bf3_prepare: S, Z, row norms, and all four split images."""
+    vgan_mask_project_forward (norm_split) followed by vgan_mmd_bf3_prepare: S, Z, row norms, and all four split images --
+    with and without the centring vector; the norms are those of the split values hi + lo."""
     rng = np.random.default_rng(n * 7 + d)
     rows_total = 3 * n
-    data = dev(rng.normal(size=(rows_total, d)).astype(np.float32))
+    data = dev((rng.normal(size=(rows_total, d)) + (5.0 if centred else 0.0)).astype(np.float32))
+    center = torch.empty(d, device="cuda")
+    ops.col_mean(data, center)
+    np.testing.assert_allclose(host(center), host(data).astype(np.float64).mean(0), rtol=1e-6, atol=1e-7)
+    center = center if centred else None
     logits = dev((rng.normal(size=(n, d)) * 2.0).astype(np.float32))
     perm = torch.as_tensor(np.stack([rng.permutation(rows_total)[:n] for _ in range(2)]).astype(np.int32)).cuda()
     cursor = torch.full((1,), 3, dtype=torch.int64, device="cuda")  # 3 % 2 -> second index row
@@ -880,14 +959,21 @@ def test_mask_project_forward_bf3_equals_two_launches(ops, n, d):
 
     a, b = buffers(), buffers()
     sel = dict(row_cursor=cursor, row_batches=2, row_stride=n)
-    ops.mask_project_forward(logits, data, perm, a["S"], None, a["Z"][:n], a["Z"][n:], a["sq"][:n], a["sq"][n:], **sel)
+    ops.mask_project_forward(logits, data, perm, a["S"], None, a["Z"][:n], a["Z"][n:], a["sq"][:n], a["sq"][n:], center=center,
+                             norm_split=True, **sel)
     ops.mmd_bf3_prepare(a["Z"], 2 * n, d, a["Zh"], a["Zl"], a["ZTh"], a["ZTl"])
     assert ops.bf3_fusable(n, d, logits.stride(0), data.stride(0), dp)
-    ops.mask_project_forward_bf3(logits, data, perm, b["S"], b["Z"], b["sq"], b["Zh"], b["Zl"], b["ZTh"], b["ZTl"], **sel)
+    ops.mask_project_forward_bf3(logits, data, perm, b["S"], b["Z"], b["sq"], b["Zh"], b["Zl"], b["ZTh"], b["ZTl"], center=center, **sel)
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert float(a["Z"][:n, :d].abs().sum()) > 0 and int((a["ZTh"] != 0).sum()) > 0
+    # what was written: Z = [X - c ; fl(U*X) - c], sq = |hi + lo|^2
+    X = host(data)[host(perm)[1]]
+    c = host(center) if centred else np.zeros(d, np.float32)
+    assert np.array_equal(host(a["Z"][:n, :d]), X - c)
+    zhat = a["Zh"].view(torch.bfloat16).double() + a["Zl"].view(torch.bfloat16).double()
+    np.testing.assert_allclose(host(a["sq"]), host((zhat * zhat).sum(1)), rtol=2e-6)
 
 
 def test_integration_stub_from_this_file():

@@ -4,8 +4,6 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
-#include <stdlib.h>
-
 #include <algorithm>
 #include <array>
 #include <cstring>
@@ -185,7 +183,8 @@ __global__ __launch_bounds__(1024) void mmd_finalize_kernel(vgan_finalize_job jo
 template <int VEC, int KW>
 __global__ __launch_bounds__(kBlock * KW, 2) void mmd_backward_kernel(const float* __restrict__ Wg, int ldw, const float* __restrict__ Z,
                                                                 int ldz, int wrow0, int nr, int ncols, int p,
-                                                                const float* __restrict__ mul, int ldmul, float* __restrict__ out,
+                                                                const float* __restrict__ mul, int ldmul,
+                                                                const float* __restrict__ mul_shift, float* __restrict__ out,
                                                                 int ldo, int kchunk, long slab_stride, vgan_finalize_job job) {
     using G = GemmTile<GT, GT, GBK * KW, KC, MC, VEC, 0, KW>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
@@ -215,11 +214,12 @@ __global__ __launch_bounds__(kBlock * KW, 2) void mmd_backward_kernel(const floa
     const int col = n0 + G::sub_col(0), colc = min(col, p - 1);
     const int r_lo = G::first_reg();
     float z_pre[G::kNumRegs], m_pre[G::kNumRegs];
+    const float mshift = mul_shift != nullptr ? mul_shift[colc] : 0.f;  // mul is stored centred (see vgan_mmd_backward)
 #pragma unroll
     for (int rr = 0; rr < G::kNumRegs; ++rr) {
         const int rowc = min(m0 + G::sub_row(0, r_lo + rr), nr - 1);
         z_pre[rr] = Z[(long)(wrow0 + rowc) * ldz + colc];
-        m_pre[rr] = mul != nullptr ? mul[(long)rowc * ldmul + colc] : 1.f;
+        m_pre[rr] = mul != nullptr ? mul[(long)rowc * ldmul + colc] + mshift : 1.f;
     }
     f32x16 acc[1][1];
     zero_acc(acc);
@@ -247,6 +247,25 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ Z, int ldz, float* _
     for (int j = threadIdx.x & 63; j < p; j += 64) s = fmaf(z[j], z[j], s);
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sq[row] = s;
+}
+
+// per-feature mean of the resident data set (float64 accumulation, fixed order): the centre that the step engine subtracts
+// from every row of the MMD operand.  Once per fit; one 64-column strip per workgroup, rows dealt round-robin to 16 waves.
+__global__ __launch_bounds__(1024) void col_mean_kernel(const float* __restrict__ data, int ldd, int rows, int d, float* __restrict__ out) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (j < d)
+        for (int r = wave; r < rows; r += 16) s += (double)data[(long)r * ldd + j];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < d) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        out[j] = (float)(t / (double)rows);
+    }
 }
 
 // ---- error text (thread-local) ---------------------------------------------------------------
@@ -350,16 +369,10 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
     return count;
 }
 
-// Workgroup shape per kernel (A/B knobs).  Measured on MI355X at n = 1024, d = 784: the Gram (two tiles per CU) is faster
-// with 256-thread workgroups (48.7 vs 57.4 us), the backward GEMM (208 tiles for 256 CUs: one per CU) with 512-thread
-// K-split workgroups and no row slabs (48.9 vs 57.4 us; 50.4 with two slabs of 256-thread workgroups).
-static int env_kw(const char* name, int dflt) {
-    const char* v = getenv(name);
-    const int k = v ? atoi(v) : dflt;
-    return k == 1 || k == 2 ? k : dflt;
-}
-static int gram_kw() { static const int kw = env_kw("VGAN_GRAM_KW", 1); return kw; }
-static int bwd_kw() { static const int kw = env_kw("VGAN_BWD_KW", 2); return kw; }
+// Workgroup shape per kernel.  Measured on MI355X at n = 1024, d = 784: the Gram (two tiles per CU) is faster with
+// 256-thread workgroups (48.7 vs 57.4 us), the backward GEMM (208 tiles for 256 CUs: one per CU) with 512-thread K-split
+// workgroups and no row slabs (48.9 vs 57.4 us; 50.4 with two slabs of 256-thread workgroups).
+constexpr int kGramKW = 1, kBwdKW = 2;
 
 template <int KW>
 static void launch_gram_kw(dim3 grid, hipStream_t s, bool vec, int calibrate, const float* Z, int ldz, const float* sq, int n, int p,
@@ -386,10 +399,7 @@ static int launch_gram(const float* Z, int ldz, const float* sq, int n, int p, c
     const TileDesc* td = reinterpret_cast<const TileDesc*>(tiles);
     const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
     dim3 grid(ntiles + extra_blocks);
-    if (gram_kw() == 2)
-        launch_gram_kw<2>(grid, s, vec, calibrate, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
-    else
-        launch_gram_kw<1>(grid, s, vec, calibrate, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+    launch_gram_kw<kGramKW>(grid, s, vec, calibrate, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -451,15 +461,16 @@ extern "C" int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int
 }
 
 extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int ldz, int wrow0, int nr, int ncols, int p,
-                                 const float* mul, int ldmul, float* out, int ldo, int splits, int64_t slab_stride,
-                                 const vgan_finalize_job* finalize, vgan_stream_t stream) {
+                                 const float* mul, int ldmul, const float* mul_shift, float* out, int ldo, int splits,
+                                 int64_t slab_stride, const vgan_finalize_job* finalize, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Wg && Z && out && nr > 0 && ncols > 0 && p > 0 && ldw >= ncols && ldz >= p && ldo >= p && wrow0 >= 0 &&
                    wrow0 + nr <= ncols);
     VGAN_CHECK_ARG(mul == nullptr || ldmul >= p);
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (ncols % 4 == 0) && (ldw % 4 == 0) && (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Wg) && aligned16(Z);
-    const int kw = bwd_kw();
+    VGAN_CHECK_ARG(mul_shift == nullptr || mul != nullptr);
+    constexpr int kw = kBwdKW;
     const int kt = GBK * kw;
     const int kchunk = ((ncols + splits - 1) / splits + kt - 1) / kt * kt;  // whole K tiles per slice (keeps 16-byte alignment)
     vgan_finalize_job job{};
@@ -468,9 +479,8 @@ extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int l
         job = *finalize;
     }
     dim3 grid(((p + GT - 1) / GT) * ((nr + GT - 1) / GT) + (finalize != nullptr ? 1 : 0), splits), block(kBlock * kw);
-#define VGAN_BWD(V, W) hipLaunchKernelGGL((mmd_backward_kernel<V, W>), grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, out, ldo, kchunk, (long)slab_stride, job)
-    if (kw == 2) { if (vec) VGAN_BWD(4, 2); else VGAN_BWD(1, 2); }
-    else { if (vec) VGAN_BWD(4, 1); else VGAN_BWD(1, 1); }
+#define VGAN_BWD(V) hipLaunchKernelGGL((mmd_backward_kernel<V, kBwdKW>), grid, block, 0, s, Wg, ldw, Z, ldz, wrow0, nr, ncols, p, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job)
+    if (vec) VGAN_BWD(4); else VGAN_BWD(1);
 #undef VGAN_BWD
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
@@ -479,6 +489,13 @@ extern "C" int vgan_mmd_backward(const float* Wg, int ldw, const float* Z, int l
 extern "C" int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Z && sq && rows > 0 && p > 0 && ldz >= p);
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((rows + 3) / 4), dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, sq, rows, p);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_col_mean(const float* data, int ldd, int rows, int d, float* out, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(data && out && rows > 0 && d > 0 && ldd >= d);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((d + 63) / 64), dim3(1024), 0, (hipStream_t)stream, data, ldd, rows, d, out);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -10,8 +10,6 @@
 //
 // Operands are prepared once per step by vgan_mmd_bf3_prepare: Z -> (Zh, Zl) row-major for the Gram and (ZTh, ZTl),
 // the transposed copy, for the backward product, whose B fragment needs 8 consecutive k (= Z rows) per lane.
-#include <stdlib.h>
-
 #include "gemm_bf3.hpp"
 #include "mmd_common.hpp"
 
@@ -304,8 +302,8 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
                                                                     const unsigned short* __restrict__ ZTl, int kn,
                                                                     const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                     int ptiles, const float* __restrict__ mul, int ldmul,
-                                                                    float* __restrict__ out, int ldo, int kchunk, long slab_stride,
-                                                                    vgan_finalize_job job) {
+                                                                    const float* __restrict__ mul_shift, float* __restrict__ out, int ldo,
+                                                                    int kchunk, long slab_stride, vgan_finalize_job job) {
     using G = GemmBF3<BK>;
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     __shared__ float rs[64];
@@ -331,11 +329,12 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
     // they would add one full memory latency to every tile
     const int col = n0 + G::sub_col(), colc = min(col, p - 1);
     float z_pre[16], m_pre[16];
+    const float mshift = mul_shift != nullptr ? mul_shift[colc] : 0.f;  // mul is stored centred (see vgan_mmd_backward)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rowc = min(m0 + G::sub_row(r), nr - 1);
         z_pre[r] = Z[(long)(wrow0 + rowc) * ldz + colc];
-        m_pre[r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] : 1.f;
+        m_pre[r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] + mshift : 1.f;
     }
     if (klen > 0) G::template run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, gx * 64, klen, lds, rs, acc);
     if (col >= p) return;
@@ -355,8 +354,8 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
                                                                       const unsigned short* __restrict__ ZTl, int kn,
                                                                       const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                       int ptiles, const float* __restrict__ mul, int ldmul,
-                                                                      float* __restrict__ out, int ldo, int kchunk, long slab_stride,
-                                                                      int nb_rows, vgan_finalize_job job) {
+                                                                      const float* __restrict__ mul_shift, float* __restrict__ out, int ldo,
+                                                                      int kchunk, long slab_stride, int nb_rows, vgan_finalize_job job) {
     using G = GemmBF3Big;  // nb_rows: rows of ZT that exist (kp); feature rows past it are clamped, their columns discarded
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     __shared__ float rs[128];
@@ -377,13 +376,14 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
     // epilogue operands requested before the main loop
     const int col = n0 + G::sub_col(), colc = min(col, p - 1);
     float z_pre[2][16], m_pre[2][16];
+    const float mshift = mul_shift != nullptr ? mul_shift[colc] : 0.f;
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rowc = min(m0 + G::sub_row(i2, r), nr - 1);
             z_pre[i2][r] = Z[(long)(wrow0 + rowc) * ldz + colc];
-            m_pre[i2][r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] : 1.f;
+            m_pre[i2][r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] + mshift : 1.f;
         }
     f32x16 acc[2];
 #pragma unroll
@@ -445,19 +445,26 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
     return VGAN_OK;
 }
 
+// the tile edge vgan_mmd_backward_bf3 runs for this shape: 128-wide tiles (half the L2 -> LDS bytes per flop) once they
+// fill the chip at least twice over, unless the caller forces one
+extern "C" int vgan_mmd_backward_bf3_tile(int nr, int p, int splits, int tile) {
+    if (tile == 64 || tile == 128) return tile;
+    const int big_tiles = ((p + 127) / 128) * ((nr + 127) / 128);
+    return big_tiles * splits >= 512 ? 128 : 64;
+}
+
 extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh, const uint16_t* ZTl, int kn,
                                      int kp, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
-                                     float* out, int ldo, int splits, int64_t slab_stride, const vgan_finalize_job* finalize,
-                                     vgan_stream_t stream) {
+                                     const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
+                                     const vgan_finalize_job* finalize, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Wh && Wl && ZTh && ZTl && Z && out && nr > 0 && p > 0 && kn > 0 && kn % 64 == 0 && kp >= p && kp % 64 == 0);
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
     VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(ZTh) && aligned16(ZTl) && ldw % 8 == 0);
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
     const int kchunk = ((kn / 64 + splits - 1) / splits) * 64;
-    // large problems: 128x128 tiles (half the L2 -> LDS bytes per flop) once they fill the chip at least twice over
     const int big_tiles = ((p + 127) / 128) * ((nr + 127) / 128);
-    static const int force_big = [] { const char* e = getenv("VGAN_BWD_TILE"); return (e && atoi(e) == 128) ? 1 : 0; }();
-    if (big_tiles * splits >= 512 || force_big) {
+    VGAN_CHECK_ARG((tile == 0 || tile == 64 || tile == 128) && (mul_shift == nullptr || mul != nullptr));
+    if (vgan_mmd_backward_bf3_tile(nr, p, splits, tile) == 128) {
         const int pt = (p + 127) / 128;
         dim3 gridb(big_tiles + (finalize != nullptr ? 1 : 0), splits);
         vgan_finalize_job jb{};
@@ -466,7 +473,7 @@ extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int
             jb = *finalize;
         }
         hipLaunchKernelGGL(mmd_backward_bf3_big_kernel, gridb, dim3(512), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, pt, mul, ldmul, out, ldo, kchunk, (long)slab_stride, kp, jb);
+                           nr, p, pt, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, kp, jb);
         VGAN_CHECK_LAUNCH();
         return VGAN_OK;
     }
@@ -478,7 +485,7 @@ extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int
     }
     dim3 grid(ptiles * ((nr + 63) / 64) + (finalize != nullptr ? 1 : 0), splits);
         hipLaunchKernelGGL(mmd_backward_bf3_kernel<64>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, ptiles, mul, ldmul, out, ldo, kchunk, (long)slab_stride, job);
+                           nr, p, ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

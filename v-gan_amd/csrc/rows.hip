@@ -26,11 +26,20 @@ struct RowSel {
     }
 };
 
+// y = fl(u * x) - c with the product ROUNDED first, as the reference forms `U * batch` (src/vgan.py:616) before any distance
+// is taken (the file is compiled with -ffp-contract=fast, which would otherwise fuse the two into one fma)
+__device__ __forceinline__ float project_centred(float u, float x, float c) {
+#pragma clang fp contract(off)
+    const float y = u * x;
+    return y - c;
+}
+
 template <bool PROJECT>
 __global__ __launch_bounds__(kBlock) void mask_forward_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
                                                              int ldd, RowSel rows, float* __restrict__ S,
                                                              float* __restrict__ U, float* __restrict__ Zx, float* __restrict__ Zy,
-                                                             int ldz, float* __restrict__ sqx, float* __restrict__ sqy, int n, int d) {
+                                                             int ldz, float* __restrict__ sqx, float* __restrict__ sqy, int n, int d,
+                                                             const float* __restrict__ center, int norm_split) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -57,12 +66,14 @@ __global__ __launch_bounds__(kBlock) void mask_forward_kernel(const float* __res
         S[(long)i * d + j] = s;
         if (U) U[(long)i * d + j] = u;
         if constexpr (PROJECT) {
-            const float xv = xr[j];
-            const float yv = u * xv;
+            const float c = center ? center[j] : 0.f;
+            const float xv = xr[j] - c;
+            const float yv = project_centred(u, xr[j], c);
             if (zx) zx[j] = xv;
             zy[j] = yv;
-            nx = fmaf(xv, xv, nx);
-            ny = fmaf(yv, yv, ny);
+            const float xn = norm_split ? split_value(xv) : xv, yn = norm_split ? split_value(yv) : yv;
+            nx = fmaf(xn, xn, nx);
+            ny = fmaf(yn, yn, ny);
         }
     }
     if constexpr (PROJECT) {
@@ -82,20 +93,22 @@ template <int NT>
 __global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
                                                                  int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ U,
                                                                  float* __restrict__ Zx, float* __restrict__ Zy, int ldz,
-                                                                 float* __restrict__ sqx, float* __restrict__ sqy, int n, int d) {
+                                                                 float* __restrict__ sqx, float* __restrict__ sqy, int n, int d,
+                                                                 const float* __restrict__ center, int norm_split) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
     const int nq = d >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(logits + (long)i * ldl);
     const float4* xr4 = reinterpret_cast<const float4*>(data + rows(i) * ldd);
-    float4 v[NT], xv[NT];
+    float4 v[NT], xv[NT], cv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int q = lane + 64 * t;
         const bool ok = q < nq;
         v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         xv[t] = xr4[min(q, nq - 1)];
+        cv[t] = center ? reinterpret_cast<const float4*>(center)[min(q, nq - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float m = -INFINITY;
 #pragma unroll
@@ -116,13 +129,24 @@ __global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* _
         if (q < nq) {
             float4 s4 = make_float4(v[t].x / sum, v[t].y / sum, v[t].z / sum, v[t].w / sum);
             float4 u4 = make_float4(s4.x < tau ? s4.x : 1.f, s4.y < tau ? s4.y : 1.f, s4.z < tau ? s4.z : 1.f, s4.w < tau ? s4.w : 1.f);
-            float4 y4 = make_float4(u4.x * xv[t].x, u4.y * xv[t].y, u4.z * xv[t].z, u4.w * xv[t].w);
+            // the MMD operand is CENTRED (a per-feature constant is subtracted from every row of [X ; U*X]: the distances
+            // are translation invariant) so that a common offset of a feature does not eat the operand's mantissa
+            const float4 x4c = make_float4(xv[t].x - cv[t].x, xv[t].y - cv[t].y, xv[t].z - cv[t].z, xv[t].w - cv[t].w);
+            const float4 y4 = make_float4(project_centred(u4.x, xv[t].x, cv[t].x), project_centred(u4.y, xv[t].y, cv[t].y), project_centred(u4.z, xv[t].z, cv[t].z),
+                                              project_centred(u4.w, xv[t].w, cv[t].w));
             reinterpret_cast<float4*>(S + (long)i * d)[q] = s4;
             if (U) reinterpret_cast<float4*>(U + (long)i * d)[q] = u4;
-            if (Zx) reinterpret_cast<float4*>(Zx + (long)i * ldz)[q] = xv[t];
+            if (Zx) reinterpret_cast<float4*>(Zx + (long)i * ldz)[q] = x4c;
             reinterpret_cast<float4*>(Zy + (long)i * ldz)[q] = y4;
-            nx += (xv[t].x * xv[t].x + xv[t].y * xv[t].y) + (xv[t].z * xv[t].z + xv[t].w * xv[t].w);
-            ny += (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
+            const float xs[4] = {x4c.x, x4c.y, x4c.z, x4c.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+            float xn[4], yn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xn[e] = norm_split ? split_value(xs[e]) : xs[e];
+                yn[e] = norm_split ? split_value(ys[e]) : ys[e];
+            }
+            nx += (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
+            ny += (yn[0] * yn[0] + yn[1] * yn[1]) + (yn[2] * yn[2] + yn[3] * yn[3]);
         }
     }
     nx = wave_sum(nx);
@@ -143,7 +167,8 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                                                                  int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ Z,
                                                                  int ldz, float* __restrict__ sq, unsigned short* __restrict__ Zh,
                                                                  unsigned short* __restrict__ Zl, int kp, unsigned short* __restrict__ ZTh,
-                                                                 unsigned short* __restrict__ ZTl, int kn, int n, int d) {
+                                                                 unsigned short* __restrict__ ZTl, int kn, int n, int d,
+                                                                 const float* __restrict__ center) {
     constexpr int R = 8;  // rows per workgroup = waves per workgroup (512 threads; 4 rows in 256 threads measured the same: 11.7 us)
     extern __shared__ __attribute__((aligned(16))) unsigned short tile[];  // [4 images: Xh, Xl, Yh, Yl][R][ldt]
     const int ldt = 4 * (d >> 2) + 8;                     // bf16 elements per tile row (8-byte stores stay aligned)
@@ -162,13 +187,14 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
         if (i < n) {
             const float4* x4 = reinterpret_cast<const float4*>(logits + (long)i * ldl);
             const float4* xr4 = reinterpret_cast<const float4*>(data + rows(i) * ldd);
-            float4 v[NT], xv[NT];
+            float4 v[NT], xv[NT], cv[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int q = lane + 64 * t;
                 const bool ok = q < nq;
                 v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                 xv[t] = xr4[min(q, nq - 1)];
+                cv[t] = center ? reinterpret_cast<const float4*>(center)[min(q, nq - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             float m = -INFINITY;
 #pragma unroll
@@ -188,19 +214,26 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                 if (q < nq) {
                     const float4 s4 = make_float4(v[t].x / sum, v[t].y / sum, v[t].z / sum, v[t].w / sum);
                     const float4 u4 = make_float4(s4.x < tau ? s4.x : 1.f, s4.y < tau ? s4.y : 1.f, s4.z < tau ? s4.z : 1.f, s4.w < tau ? s4.w : 1.f);
-                    const float4 y4 = make_float4(u4.x * xv[t].x, u4.y * xv[t].y, u4.z * xv[t].z, u4.w * xv[t].w);
+                    // centred operand (see mask_forward_vec_kernel); the row norms are those of the SPLIT values hi + lo, the
+                    // numbers the Gram kernel actually multiplies, so that L = s_i + s_j - 2 g is |zhat_i - zhat_j|^2 exactly
+                    const float4 x4c = make_float4(xv[t].x - cv[t].x, xv[t].y - cv[t].y, xv[t].z - cv[t].z, xv[t].w - cv[t].w);
+                    const float4 y4 = make_float4(project_centred(u4.x, xv[t].x, cv[t].x), project_centred(u4.y, xv[t].y, cv[t].y), project_centred(u4.z, xv[t].z, cv[t].z),
+                                              project_centred(u4.w, xv[t].w, cv[t].w));
                     reinterpret_cast<float4*>(S + (long)i * d)[q] = s4;
-                    reinterpret_cast<float4*>(Z + (long)i * ldz)[q] = xv[t];
+                    reinterpret_cast<float4*>(Z + (long)i * ldz)[q] = x4c;
                     reinterpret_cast<float4*>(Z + (long)(n + i) * ldz)[q] = y4;
-                    nx += (xv[t].x * xv[t].x + xv[t].y * xv[t].y) + (xv[t].z * xv[t].z + xv[t].w * xv[t].w);
-                    ny += (y4.x * y4.x + y4.y * y4.y) + (y4.z * y4.z + y4.w * y4.w);
-                    const float xs[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+                    const float xs[4] = {x4c.x, x4c.y, x4c.z, x4c.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
                     unsigned short h[2][4], l[2][4];
+                    float xn[4], yn[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         split_bf16(xs[e], h[0][e], l[0][e]);
                         split_bf16(ys[e], h[1][e], l[1][e]);
+                        xn[e] = bf16_val(h[0][e]) + bf16_val(l[0][e]);
+                        yn[e] = bf16_val(h[1][e]) + bf16_val(l[1][e]);
                     }
+                    nx += (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
+                    ny += (yn[0] * yn[0] + yn[1] * yn[1]) + (yn[2] * yn[2] + yn[3] * yn[3]);
 #pragma unroll
                     for (int im = 0; im < 2; ++im) {  // 0: X row i, 1: Y row n + i
                         const uint2 ph = make_uint2((unsigned)h[im][0] | ((unsigned)h[im][1] << 16), (unsigned)h[im][2] | ((unsigned)h[im][3] << 16));
@@ -372,21 +405,22 @@ using namespace vgan;
 extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                          const uint64_t* row_cursor, int row_batches, int row_stride, int row_offset, float* S,
                                          float* U, float* Zx, float* Zy, int ldz, float* sqx, float* sqy, int n, int d,
-                                         vgan_stream_t stream) {
+                                         const float* center, int norm_split, vgan_stream_t stream) {
     VGAN_CHECK_ARG(logits && data && S && Zy && sqy && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
     VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && row_offset >= 0);
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
     const dim3 grid((n + kRowsPerBlock - 1) / kRowsPerBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (d % 4 == 0) && (d <= 1024) && (ldl % 4 == 0) && (ldd % 4 == 0) && (ldz % 4 == 0) && aligned16(logits) &&
-                     aligned16(data) && aligned16(S) && (U == nullptr || aligned16(U)) && (Zx == nullptr || aligned16(Zx)) && aligned16(Zy);
+                     aligned16(data) && aligned16(S) && (U == nullptr || aligned16(U)) && (Zx == nullptr || aligned16(Zx)) && aligned16(Zy) && (center == nullptr || aligned16(center));
     if (vec) {
         const int nt = (d / 4 + 63) / 64;
-#define VGAN_LAUNCH_FWD(NT) hipLaunchKernelGGL(mask_forward_vec_kernel<NT>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d)
+#define VGAN_LAUNCH_FWD(NT) hipLaunchKernelGGL(mask_forward_vec_kernel<NT>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d, center, norm_split)
         if (nt == 1) VGAN_LAUNCH_FWD(1); else if (nt == 2) VGAN_LAUNCH_FWD(2); else if (nt == 3) VGAN_LAUNCH_FWD(3); else VGAN_LAUNCH_FWD(4);
 #undef VGAN_LAUNCH_FWD
     } else
-        hipLaunchKernelGGL(mask_forward_kernel<true>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d);
+        hipLaunchKernelGGL(mask_forward_kernel<true>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d, center,
+                           norm_split);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -394,13 +428,13 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
 extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                              const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z, int ldz,
                                              float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh, uint16_t* ZTl, int kn,
-                                             int n, int d, vgan_stream_t stream) {
+                                             int n, int d, const float* center, vgan_stream_t stream) {
     VGAN_CHECK_ARG(logits && data && S && Z && sq && Zh && Zl && ZTh && ZTl && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
     VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && kp >= d && kp % 64 == 0 && kn >= 2 * n && kn % 64 == 0);
     // shape contract of the fused path (callers fall back to vgan_mask_project_forward + vgan_mmd_bf3_prepare otherwise)
     VGAN_CHECK_ARG(d % 4 == 0 && d <= 1024 && n % 8 == 0 && ldl % 4 == 0 && ldd % 4 == 0 && ldz % 4 == 0);
     VGAN_CHECK_ARG(aligned16(logits) && aligned16(data) && aligned16(S) && aligned16(Z) && aligned16(Zh) && aligned16(Zl) &&
-                   aligned16(ZTh) && aligned16(ZTl));
+                   aligned16(ZTh) && aligned16(ZTl) && (center == nullptr || aligned16(center)));
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, 0};
     const dim3 grid(8 * ((n / 8 + 7) / 8)), block(512);
     const size_t shmem = (size_t)4 * 8 * (d + 8) * sizeof(unsigned short);
@@ -413,7 +447,7 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_bf3_kernel<NT>),                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                      \
         hipLaunchKernelGGL(mask_forward_bf3_kernel<NT>, grid, block, shmem, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, Zh, Zl, kp, \
-                           ZTh, ZTl, kn, n, d);                                                                                     \
+                           ZTh, ZTl, kn, n, d, center);                                                                             \
     } while (0)
     if (nt == 1) VGAN_LAUNCH_FWD3(1); else if (nt == 2) VGAN_LAUNCH_FWD3(2); else if (nt == 3) VGAN_LAUNCH_FWD3(3); else VGAN_LAUNCH_FWD3(4);
 #undef VGAN_LAUNCH_FWD3
@@ -424,7 +458,7 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
 extern "C" int vgan_upper_softmax_forward(const float* logits, int ldl, float* S, float* U, int n, int d, vgan_stream_t stream) {
     VGAN_CHECK_ARG(logits && S && n > 0 && d > 0 && ldl >= d);
     hipLaunchKernelGGL(mask_forward_kernel<false>, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0,
-                       (hipStream_t)stream, logits, ldl, nullptr, 0, RowSel{nullptr, nullptr, 1, 0, 0}, S, U, nullptr, nullptr, 0, nullptr, nullptr, n, d);
+                       (hipStream_t)stream, logits, ldl, nullptr, 0, RowSel{nullptr, nullptr, 1, 0, 0}, S, U, nullptr, nullptr, 0, nullptr, nullptr, n, d, nullptr, 0);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -107,6 +107,13 @@ __device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned
     lo = bf16_bits(v - bf16_val(hi));
 }
 
+// the value the split operands carry: hi + lo (16 significant bits of v); row norms of the bf16x3 kernels are taken from it
+__device__ __forceinline__ float split_value(float v) {
+    unsigned short hi, lo;
+    split_bf16(v, hi, lo);
+    return bf16_val(hi) + bf16_val(lo);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace vgan

@@ -36,7 +36,8 @@ SIGNATURES = {
     "vgan_linear_backward_input": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _i, _i64, _p, _i, _p, _i, _i, _i, _i, _i64, _p]),
     "vgan_reduce_slabs": (_i, [_p, _i64, _i, _p, _i64, _p]),
-    "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
+    "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p]),
+    "vgan_col_mean": (_i, [_p, _i, _i, _i, _p, _p]),
     "vgan_gather_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
     "vgan_mask_backward": (_i, [_p, _i, _i, _i64, _p, _i, _p, _f, _i, _p, _i, _i, _i, _p]),
     "vgan_colmax_partial": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
@@ -51,17 +52,18 @@ SIGNATURES = {
     "vgan_mmd_reduce": (_i, [_p, _p, _i, _p, _i, _p]),
     "vgan_mmd_set_bandwidth": (_i, [_p, _i, _p, _p]),
     "vgan_mmd_loss": (_i, [_p, _p, _i, _i, _f, _p, _p, _f, _p, _p]),
-    "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p, _p]),
+    "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _p, _p]),
     "vgan_mmd_bf3_prepare": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
-    "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i64, _p, _p]),
+    "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p]),
+    "vgan_mmd_backward_bf3_tile": (_i, [_i, _i, _i, _i]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_noise_normal": (_i, [_p, _i, _i, _i, _i, _u64, _p, _u64, _p]),
     "vgan_homogeneous_pack": (_i, [_p, _i, _i, _i, _p]),
     "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _u64, _p, _p]),
     "vgan_gemm_grouped": (_i, [_p, _i, _p]),
-    "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p]),
+    "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p]),
     "vgan_mse_grad": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
     "vgan_sum_f64": (_i, [_p, _i, ctypes.c_double, _p, _i, _p]),
     "vgan_rbf_kernel_matrix": (_i, [_p, _i, _i, _i, _p, _f, _p, _i, _p]),
@@ -69,7 +71,7 @@ SIGNATURES = {
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

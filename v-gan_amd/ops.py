@@ -89,8 +89,17 @@ class HipOps:
                    "vgan_reduce_slabs")
 
     # ---- upper_softmax / projection ------------------------------------------------------------
+    def col_mean(self, data, out):
+        """out[d] = per-feature mean of data [rows, d]: the centre the step engine subtracts from the MMD operand."""
+        _mat(data, "data"), _vec(out, "out")
+        rows, d = data.shape
+        assert out.numel() >= d
+        _lib.check(self.lib.vgan_col_mean(_ptr(data), data.stride(0), rows, d, _ptr(out), self._stream()), "vgan_col_mean")
+
     def mask_project_forward(self, logits, data, rows, S, U, Zx, Zy, sqx, sqy, row_cursor=None, row_batches=1, row_stride=0,
-                             row_offset=0):
+                             row_offset=0, center=None, norm_split=False):
+        """center [d]: subtracted from every row written to Zx / Zy; norm_split: sqx / sqy are the norms of the bf16 hi + lo
+        split of those rows (what mmd_gram_bf3 needs)."""
         _mat(logits, "logits"), _mat(data, "data"), _mat(Zy, "Zy")
         n, d = logits.shape
         assert S.is_contiguous() and S.shape == (n, d) and (U is None or (U.is_contiguous() and U.shape == (n, d)))
@@ -99,16 +108,17 @@ class HipOps:
             _vec(rows, "rows", torch.int32)
         _lib.check(self.lib.vgan_mask_project_forward(_ptr(logits), logits.stride(0), _ptr(data), data.stride(0), _ptr(rows),
                                                       _ptr(row_cursor), int(row_batches), int(row_stride), int(row_offset), _ptr(S), _ptr(U), _ptr(Zx), _ptr(Zy), Zy.stride(0), _ptr(sqx), _ptr(sqy),
-                                                      n, d, self._stream()), "vgan_mask_project_forward")
+                                                      n, d, _ptr(center), int(bool(norm_split)), self._stream()), "vgan_mask_project_forward")
 
-    def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0):
+    def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
+                                 center=None):
         """mask_project_forward + mmd_bf3_prepare in one launch (shape contract in include/vgan_hip.h; see bf3_fusable)."""
         _mat(logits, "logits"), _mat(data, "data"), _mat(Z, "Z")
         n, d = logits.shape
         _lib.check(self.lib.vgan_mask_project_forward_bf3(_ptr(logits), logits.stride(0), _ptr(data), data.stride(0), _ptr(rows),
                                                           _ptr(row_cursor), int(row_batches), int(row_stride), _ptr(S), _ptr(Z), Z.stride(0),
                                                           _ptr(sq), _ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(ZTh), _ptr(ZTl), ZTh.stride(0),
-                                                          n, d, self._stream()), "vgan_mask_project_forward_bf3")
+                                                          n, d, _ptr(center), self._stream()), "vgan_mask_project_forward_bf3")
 
     @staticmethod
     def bf3_fusable(n, d, *lds):
@@ -208,13 +218,13 @@ class HipOps:
         _lib.check(self.lib.vgan_mmd_loss(_ptr(stats), _ptr(colkey), int(n), int(d), float(weight), _ptr(loss), _ptr(loss_accum),
                                           float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_loss")
 
-    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0, finalize=None):
+    def mmd_backward(self, Wg, Z, wrow0, nr, ncols, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None):
         """splits > 1: `out` is slab 0 of `splits` partial slabs `slab_stride` elements apart.  finalize: a finalize_job()
-        that one extra workgroup of the launch executes."""
+        that one extra workgroup of the launch executes.  mul_shift [p]: added to `mul` (which is stored centred)."""
         _mat(Wg, "Wg"), _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         _lib.check(self.lib.vgan_mmd_backward(_ptr(Wg), Wg.stride(0), _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(ncols), int(p),
-                                              _ptr(mul), ldmul, _ptr(out), out.stride(0), int(splits), int(slab_stride),
+                                              _ptr(mul), ldmul, _ptr(mul_shift), _ptr(out), out.stride(0), int(splits), int(slab_stride),
                                               ctypes.byref(finalize) if finalize is not None else None, self._stream()),
                    "vgan_mmd_backward")
 
@@ -237,14 +247,20 @@ class HipOps:
                                               S.stride(0) if S is not None else 0, int(bool(from_softmax)), int(row_offset),
                                               _ptr(colpart), nrows, d, self._stream()), "vgan_mmd_gram_bf3")
 
-    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None):
+    def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
+                         tile=0):
+        """tile: 0 = the library's choice between its 64- and 128-wide tiles, or 64 / 128 to force one."""
         _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         _lib.check(self.lib.vgan_mmd_backward_bf3(_ptr(Wh), _ptr(Wl), Wh.stride(0), _ptr(ZTh), _ptr(ZTl), ZTh.stride(0),
                                                   ZTh.shape[0], _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul,
-                                                  _ptr(out), out.stride(0), int(splits), int(slab_stride),
+                                                  _ptr(mul_shift), _ptr(out), out.stride(0), int(splits), int(slab_stride), int(tile),
                                                   ctypes.byref(finalize) if finalize is not None else None, self._stream()),
                    "vgan_mmd_backward_bf3")
+
+    def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
+        """Tile edge (64 / 128) mmd_backward_bf3 runs for this shape (host-side query of the library's rule)."""
+        return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 
     def gemm_grouped(self, problems):
         """problems: up to 4 tuples (kind, A, B, C) with kind in "NN" (C = A.B), "NT" (C = A.B^T), "TN" (C = A^T.B); 2-D float32

@@ -12,7 +12,7 @@ dp = d rounded up to 4, L = latent size):
   data [Ntrain, d]                        whole training set, resident; batches are gathered by
                                           index inside the mask/projection kernel
   perm [batches_per_epoch, n] int32       this epoch's shuffled indices
-  Z [2n, dp]  sq [2n]                     MMD operand [X_batch ; U*X_batch] and its row norms
+  Z [2n, dp]  sq [2n]                     MMD operand [X_batch - c ; U*X_batch - c] (c = per-feature data mean) and its row norms
   Wg [nl, 2n]                             gradient weights of this rank's Y rows (never the 5x2nx2n K)
   S [nl, d], gU [slabs, nl, dp], dlogits  mask softmax, split-K slabs of dY*X, logits gradient
 
@@ -86,7 +86,7 @@ class FlatParams:
 class NoKLStepEngine:
     def __init__(self, ops, generator, data, batch_size, batches_per_epoch, lr=0.007, weight_decay=0.04, penalty_weight=10.0,
                  seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None,
-                 generator_mode=None, force_exchange=False, mmd_precision=None):
+                 generator_mode=None, force_exchange=False, mmd_precision=None, center_operand=True):
         self.ops = ops
         self.dev = data.device
         self.rank, self.world, self.group = rank, world, group
@@ -176,11 +176,21 @@ class NoKLStepEngine:
         if self.precision == "auto":
             self.precision = "bf16x3" if 2 * n * d >= (1 << 20) else "fp32"
         self.bf3 = self.precision == "bf16x3"
+        # The MMD operand is CENTRED: Z = [X - c ; U*X - c] with c = the per-feature mean of the data set (once per fit).
+        # cdist(Z, Z)**2 and the backward expression sum_j W_ij (z_i - z_j) are translation invariant, so nothing changes in
+        # exact arithmetic, but a feature's common offset mu no longer costs (mu/sigma)^2 of the operands' mantissa in
+        # L = s_i + s_j - 2 g -- which decides the bf16x3 mode (16-bit operands) on unstandardised data.  Only `U * batch`'s
+        # product rule needs the batch itself: the backward kernels add c back to their multiplier (`mul_shift`).
+        self.center = torch.zeros(dp, **f32)
+        if center_operand:
+            ops.col_mean(data, self.center)
+        self.bwd_tile = int(os.environ.get("VGAN_BWD_TILE", "0"))  # measurement knob: force the 64- / 128-wide bf16x3 backward tile
         self._fin = None  # finalize job (raw pointers of the tensors below), built at first use
         self.S = torch.zeros(n, d, **f32)
         self.S_own = self.S[self.lo:self.lo + nl]
         self.Z = torch.zeros(2 * n, dp, **f32)
-        self.sqn = torch.zeros(2 * n, **f32)
+        self.sqn = torch.zeros(2 * n, **f32)   # bf16x3 mode: norms of the split values hi + lo (what its Gram multiplies)
+        self.sq_cal = torch.zeros(2 * n, **f32) if self.bf3 else self.sqn  # fp32 norms for the (fp32) calibration launch
         self.Wg = torch.zeros(nl, 2 * n, **f32)
         # The backward GEMM contracts over the 2n rows of Z; it can be sliced into row slabs that the mask-backward kernel
         # sums.  Measured at c3: 2 slabs pay for the split-bf16 kernel (24.3 vs 29.6 us; 3 and 4 spill into a second round
@@ -334,15 +344,17 @@ class NoKLStepEngine:
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
         if self.fused_prepare:  # mask/projection and the bf16x3 operand split in one launch
             ops.mask_project_forward_bf3(self.logits, self.data, self.perm, self.S, self.Z, self.sqn, self.Zh, self.Zl, self.ZTh, self.ZTl,
-                                         **rowsel)
+                                         center=self.center, **rowsel)
             return
         ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n], self.sqn[n:],
-                                 row_offset=0, **rowsel)
+                                 row_offset=0, center=self.center, norm_split=self.bf3, **rowsel)
 
     def _calibrate(self):
         """First-call bandwidth (src/models/Mmd_loss_constrained.py:16-20): sum(L) / (N^2 - N)."""
         ops = self.ops
-        ops.mmd_gram(self.Z, self.sqn, self.n, self.dp, None, self.tiles_cal, True, None, 0, self.partial)
+        if self.bf3:  # sqn holds the norms of the split values; the calibration launch is the fp32 kernel on Z itself
+            ops.row_sqnorm(self.Z, self.sq_cal, self.dp)
+        ops.mmd_gram(self.Z, self.sq_cal, self.n, self.dp, None, self.tiles_cal, True, None, 0, self.partial)
         ops.mmd_reduce(self.partial, self.tiles_cal, self.stats, True)
         ops.mmd_set_bandwidth(self.stats, self.n, self.bw)
         self.has_bw = True
@@ -370,10 +382,11 @@ class NoKLStepEngine:
         fin = self._fin
         if bf3:
             ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
-                                 gstride, fin)
+                                 gstride, fin, mul_shift=self.center, tile=self.bwd_tile)
             ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         else:
-            ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride, fin)
+            ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride, fin,
+                             mul_shift=self.center)
             ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         self._generator_backward_update(dist)
 
