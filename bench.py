@@ -283,6 +283,7 @@ def main():
             run_steps(eng, args.warmup, 0)
             torch.cuda.synchronize()
         eng.epoch_loss()
+        eng.first_timed_step = eng.steps_done  # training steps already taken: `mean_loss` below is the mean over the NEXT K steps
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -356,7 +357,7 @@ def main():
         e32, _, _, el32, ml32 = timed_leg(mmd_precision="fp32")
         k32 = kernel_rooflines(e32)
         fp32_block = {"value": args.steps / el32, "unit": "steps/s", "ms_per_step": 1e3 * el32 / args.steps, "steps": args.steps,
-                      "warmup": args.warmup, "mmd_precision": "fp32", "mean_loss": ml32, "dtype": "f32 (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
+                      "warmup": args.warmup, "mmd_precision": "fp32", "mean_loss": ml32, "first_timed_step": e32.first_timed_step, "dtype": "f32 (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
                       "roofline": roofline_of(e32, k32, args.steps / el32)}
         del e32
         torch.cuda.empty_cache()
@@ -371,7 +372,7 @@ def main():
                       "the same step with the fp32 MFMA is timed in `fp32_mode`") if eng.bf3 else "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD, "global_batch": N_BATCH, "features": D_FEAT, "latent": eng.L,
                        "rows_per_gpu": eng.nl, "parallelism": f"dp{world} (row-sharded Gram, replicated generator)",
-                       "hip_graph": bool(use_graph), "mean_loss": mean_loss, "prewarm_s": args.prewarm_seconds,
+                       "hip_graph": bool(use_graph), "mean_loss": mean_loss, "first_timed_step": eng.first_timed_step, "prewarm_s": args.prewarm_seconds,
                        "generator": eng.mode, "mmd_precision": eng.precision, "gram_tile": eng.gram_tile},
         }
         out["roofline"] = roofline_of(eng, kern, steps_per_s)

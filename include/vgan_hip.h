@@ -146,6 +146,14 @@ int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int tile, in
 int vgan_mmd_gram(const float* Z, int ldz, const float* sq, int n, int p, const float* bw,
                   const int32_t* tiles, int ntiles, int calibrate,
                   float* Wg, int ldw, int wrow0, float* partial, vgan_stream_t stream);
+/* vgan_mmd_gram (calibrate = 0) for an RBF with other than the reference's defaults -- RBF(n_kernels, mul_factor),
+ * Mmd_loss_constrained.py:7-13: K = sum_k exp(-L / (bw * multipliers[k])), one exp per kernel (the default
+ * n_kernels = 5, mul_factor = 2 runs the one-exp squaring chain of vgan_mmd_gram).  multipliers is a HOST array of
+ * n_kernels <= VGAN_RBF_MAX_KERNELS positive floats (mul_factor ** (k - n_kernels // 2)). */
+#define VGAN_RBF_MAX_KERNELS 8
+int vgan_mmd_gram_general(const float* Z, int ldz, const float* sq, int n, int p, const float* bw,
+                          const int32_t* tiles, int ntiles, const float* multipliers, int n_kernels,
+                          float* Wg, int ldw, int wrow0, float* partial, vgan_stream_t stream);
 /* vgan_mmd_gram (calibrate = 0) and vgan_colmax_partial in ONE launch: the column arg-max cells run in surplus
  * workgroups behind the Gram tiles (they are independent of each other, and the Gram grid leaves CUs idle in its
  * tail).  Arguments as in the two separate calls; colpart has vgan_colmax_chunks(nrows)*d entries. */
@@ -327,6 +335,13 @@ int vgan_sum_f64(const double* in, int count, double scale, float* out, int accu
  * ------------------------------------------------------------------------------------------- */
 int vgan_rbf_kernel_matrix(const float* Z, int ldz, int m, int p, const float* sq, float alpha, float* K, int ldk,
                            vgan_stream_t stream);
+/* RBF.forward(Z) -> K [m, m]  (src/models/Mmd_loss_constrained.py:24-26) for callers of the stand-alone module:
+ * K[i,j] = sum_k exp(-|z_i - z_j|^2 / (bw[0] * multipliers[k])); bw is a DEVICE scalar (the frozen bandwidth),
+ * multipliers a HOST array.  dK (may be NULL) receives dK/dL = -sum_k exp(..)/(bw multipliers[k]), what the module's
+ * autograd multiplies the upstream gradient with before vgan_mmd_backward. */
+int vgan_rbf_multi_kernel_matrix(const float* Z, int ldz, int m, int p, const float* sq, const float* bw,
+                                 const float* multipliers, int n_kernels, float* K, int ldk, float* dK, int lddk,
+                                 vgan_stream_t stream);
 int vgan_rows_dot(const float* A, int lda, const float* B, int ldb, double* out, int rows, int cols,
                   vgan_stream_t stream);
 

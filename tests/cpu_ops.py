@@ -175,11 +175,27 @@ class CpuOps:
     def row_sqnorm(self, Z, sq, p):
         sq.copy_(torch.as_tensor((_np(Z)[:, :p].astype(np.float64) ** 2).sum(1)))
 
-    def mmd_gram(self, Z, sq, n, p, bw, tiles, calibrate, Wg, wrow0, partial):
+    def mmd_gram_general(self, Z, sq, n, p, bw, tiles, multipliers, Wg, wrow0, partial):
+        self.mmd_gram(Z, sq, n, p, bw, tiles, False, Wg, wrow0, partial, multipliers=multipliers)
+
+    def rbf_multi_kernel_matrix(self, Z, sq, bw, multipliers, K, dK=None):
+        z = _np(Z).astype(np.float64)
+        s = (z * z).sum(1)
+        L = np.maximum(s[:, None] + s[None, :] - 2.0 * z @ z.T, 0.0)
+        scales = (np.float32(float(bw.reshape(-1)[0])) * np.asarray(multipliers, dtype=np.float32)).astype(np.float64)
+        K[:, :z.shape[0]].copy_(torch.as_tensor(sum(np.exp(-L / sc) for sc in scales)))
+        if dK is not None:
+            dK[:, :z.shape[0]].copy_(torch.as_tensor(sum(-np.exp(-L / sc) / sc for sc in scales)))
+
+    def mmd_gram(self, Z, sq, n, p, bw, tiles, calibrate, Wg, wrow0, partial, multipliers=None):
         z = _np(Z)[:, :p].astype(np.float64)
         s = _np(sq).astype(np.float64)
         T = 64
         bwv = float(bw.reshape(-1)[0]) if not calibrate else None
+        scales = None
+        if not calibrate:
+            scales = (orc.rbf_scales(bwv, np.float64) if multipliers is None else
+                      (np.float32(bwv) * np.asarray(multipliers, dtype=np.float32)).astype(np.float64))
         part = np.zeros((tiles.shape[0], 4), dtype=np.float32)
         for t, (r0, c0, rlim, clim, fl, *_rest) in enumerate(tiles.tolist()):
             ri, cj = np.arange(r0, min(r0 + T, rlim)), np.arange(c0, min(c0 + T, clim))
@@ -189,7 +205,7 @@ class CpuOps:
                 continue
             K = np.zeros_like(L)
             dK = np.zeros_like(L)
-            for sc in orc.rbf_scales(bwv, np.float64):
+            for sc in scales:
                 e = np.exp(-L / sc)
                 K += e
                 dK -= e / sc

@@ -361,6 +361,56 @@ def test_modules_autograd_matches_port(ops):
     del port
 
 
+@pytest.mark.parametrize("nk,mf", [(5, 2.0), (3, 3.0), (6, 1.5), (1, 2.0)])
+def test_rbf_module_forward_matrix_and_general_kernels(ops, nk, mf):
+    """The operator boundary of src/models/Mmd_loss_constrained.py:5-26 beyond the fused default: RBF(n_kernels, mul_factor)
+    .forward(Z) returns the N x N kernel matrix (first call calibrates and freezes the bandwidth) with autograd to Z, and
+    MMDLossConstrained runs with any such kernel -- against the float64 op-for-op port (oracle/torch_port.py)."""
+    from oracle import torch_port as port
+    from src.models.Mmd_loss_constrained import MMDLossConstrained, RBF
+    rng = np.random.default_rng(nk * 10 + int(mf * 10))
+    N, p = 150, 22
+    Z = rng.normal(size=(N, p)).astype(np.float32)
+    k = RBF(n_kernels=nk, mul_factor=mf)
+    assert torch.equal(k.bandwidth_multipliers, mf ** (torch.arange(nk) - nk // 2))
+    Zt = dev(Z).requires_grad_(True)
+    K = k(Zt)
+    pk = port.PortRBF(nk, mf)
+    Zr = torch.tensor(Z, dtype=torch.float64, requires_grad=True)
+    Kr = pk(Zr)
+    assert K.shape == (N, N)
+    np.testing.assert_allclose(float(k.bandwidth), float(pk.bandwidth), rtol=1e-5)
+    np.testing.assert_allclose(host(K), Kr.detach().numpy(), rtol=0, atol=2e-5)
+    G = rng.normal(size=(N, N)).astype(np.float32)
+    (K * dev(G)).sum().backward()
+    (Kr * torch.tensor(G, dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(host(Zt.grad), Zr.grad.numpy(), rtol=0, atol=1e-3 * float(Zr.grad.abs().max()))
+    # second call: frozen bandwidth (Mmd_loss_constrained.py:16-22)
+    K2 = k(dev(Z * 0.5))
+    np.testing.assert_allclose(host(K2), pk(torch.tensor(Z * 0.5, dtype=torch.float64)).numpy(), rtol=0, atol=2e-5)
+    # the loss with this kernel, gradient to both X and Y
+    n = 70
+    X = rng.normal(size=(n, p)).astype(np.float32)
+    Y = (X * rng.uniform(0.2, 1.0, size=(n, p))).astype(np.float32)
+    U = rng.uniform(0.01, 1.0, size=(n, p)).astype(np.float32)
+    loss_fn = MMDLossConstrained(weight=3.0, kernel=RBF(n_kernels=nk, mul_factor=mf))
+    Xt, Yt = dev(X).requires_grad_(True), dev(Y).requires_grad_(True)
+    loss = loss_fn(Xt, Yt, dev(U))
+    loss.backward()
+    Xr, Yr = torch.tensor(X, dtype=torch.float64, requires_grad=True), torch.tensor(Y, dtype=torch.float64, requires_grad=True)
+    pk2 = port.PortRBF(nk, mf)
+    lr = port.port_mmd_loss(pk2, Xr, Yr, torch.tensor(U, dtype=torch.float64), 3.0)
+    lr.backward()
+    assert abs(float(loss.detach()) - float(lr.detach())) < 2e-5
+    np.testing.assert_allclose(float(loss_fn.bandwidth), float(pk2.bandwidth), rtol=1e-5)
+    for got, ref in ((Xt.grad, Xr.grad), (Yt.grad, Yr.grad)):
+        np.testing.assert_allclose(host(got), ref.numpy(), rtol=0, atol=1e-3 * float(ref.abs().max()))
+    with pytest.raises(ValueError):
+        loss_fn(dev(X), dev(Y[:10]), dev(U))
+    with pytest.raises(ValueError):
+        RBF(n_kernels=9)
+
+
 def test_fit_drop_in_matches_reference_run():
     """VGAN_no_kl(...).fit(X) through the reference's import path, with the noise drawn from torch's CPU
     generator like the reference's CPU path: same seed -> same init, same shuffles, same noise, so the
@@ -675,6 +725,64 @@ def test_adversarial_operands_whole_step_vs_fp64(ops, case, precision):
     for i in range(8):
         ref = want["grads"][i]
         np.testing.assert_allclose(host(eng.grad_view(i)), ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-12), err_msg=f"param {i}")
+
+
+# ---- a long trajectory at the metric's size against the fp32 CPU port ------------------------------
+C3_TRAJ_STEPS = 200
+_c3_port_cache = {}
+
+
+def c3_port_trajectory():
+    """200 steps of the op-for-op PyTorch-CPU port (fp32, the reference's own arithmetic) at d=784, batch=1024 on recorded
+    batches and noise; computed once per session (~20 s on the GPU box's cores) and shared by both precision modes."""
+    if not _c3_port_cache:
+        from oracle import torch_port as port
+        n, d = 1024, 784
+        L = orc.latent_size(d)
+        data = orc.synthetic_dataset("c3", rows=4 * n)
+        params = orc.synthetic_generator_params(d)
+        rng = np.random.default_rng(2024)
+        idx = np.stack([rng.permutation(4 * n)[:n] for _ in range(C3_TRAJ_STEPS)])
+        noise = rng.normal(size=(C3_TRAJ_STEPS, n, L)).astype(np.float32)
+        mask_noise = rng.normal(size=(500, L)).astype(np.float32)
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        tr = port.PortNoKL(params)
+        losses = [tr.step(torch.as_tensor(data[idx[t]]), torch.as_tensor(noise[t])) for t in range(C3_TRAJ_STEPS)]
+        with torch.no_grad():
+            masks = (tr.generator(torch.as_tensor(mask_noise)) >= 1.0 / d).numpy()
+        _c3_port_cache.update(data=data, params=params, idx=idx, noise=noise, mask_noise=mask_noise, losses=np.array(losses),
+                              masks=masks, final=[p.detach().numpy().copy() for p in tr.params], bw=float(tr.kernel.bandwidth))
+    return _c3_port_cache
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_trajectory_c3_200_steps_vs_cpu_port(ops, precision):
+    """200 training steps at the metric's configuration (d=784, batch=1024), HIP-graph replayed, against the fp32 CPU port
+    on identical batches and noise, in both precision modes: EVERY step's loss within the 1e-4 bar (so the first step
+    beyond it, if any, fails the test and is printed), the trained parameters within 2e-4, and the 500 x 784 subspace
+    masks sampled from the trained generator within 0.2 % of the port's (threshold ties, cf. oracle_step_with_decisions)."""
+    c = c3_port_trajectory()
+    n, d = 1024, 784
+    eng, _ = make_engine(ops, c["params"], c["data"], n, nb=1, graph=True, mmd_precision=precision)
+    hist = torch.zeros(C3_TRAJ_STEPS, device="cuda")
+    for t in range(C3_TRAJ_STEPS):
+        eng.set_epoch_batches(torch.as_tensor(c["idx"][t:t + 1].astype(np.int64)))
+        eng.set_noise(torch.as_tensor(c["noise"][t]))
+        eng.step()
+        hist[t:t + 1].copy_(eng.loss)
+    diff = np.abs(host(hist) - c["losses"])
+    over = np.nonzero(diff > 1e-4)[0]
+    print(f"[c3 trajectory, {precision}] max |dloss| = {diff.max():.2e} at step {int(diff.argmax())}; loss {c['losses'][0]:.4f} -> "
+          f"{c['losses'][-1]:.4f}; first step over the 1e-4 bar: {int(over[0]) if over.size else None}")
+    assert over.size == 0, f"first divergence at step {int(over[0])}: |dloss| = {diff[over[0]]:.2e}"
+    np.testing.assert_allclose(float(eng.bw), c["bw"], rtol=1e-5)
+    for i in range(8):
+        np.testing.assert_allclose(host(eng.fp.view(eng.fp.flat, i)), c["final"][i], rtol=0, atol=2e-4)
+    logits = eng.generator_logits(torch.as_tensor(c["mask_noise"]))
+    S, U = torch.empty_like(logits), torch.empty_like(logits)
+    ops.upper_softmax_forward(logits, S, U)
+    hamming = float(((host(U) >= np.float32(1.0 / d)) != c["masks"]).mean())
+    assert hamming < 2e-3, hamming
 
 
 # ---- BASELINE.json configs[3] / configs[4] at their full single-GPU sizes -------------------------------------------

@@ -21,11 +21,20 @@ constexpr int GBK = 32;  // 128-byte row segments per staging load (one full L2 
 // CALIB: only sum of L (first-call bandwidth).  Otherwise: sum of K = t + t^2 + t^4 + t^8 + t^16 with
 // t = exp(-L / (4 bw)), i.e. sum_k exp(-L / (bw m_k)), m = {4, 2, 1, .5, .25}, and (optionally) the
 // gradient weights Wg = sgn * (2/n^2) * dK/dL with dK/dL = -(1/bw) (t/4 + t^2/2 + t^4 + 2 t^8 + 4 t^16).
-template <int VEC, bool CALIB, int KW>
+// GEN: an RBF with other than the reference's default (n_kernels = 5, mul_factor = 2) -- RBF(n_kernels, mul_factor),
+// Mmd_loss_constrained.py:7-13: one exp per kernel, scales bw * mult[k] rounded to float32 like the reference's
+// `bandwidth * bandwidth_multipliers`.  The default RBF keeps the one-exp squaring chain.
+struct RbfMults {
+    int nk;
+    float mult[VGAN_RBF_MAX_KERNELS];
+};
+
+template <int VEC, bool CALIB, int KW, bool GEN = false>
 __global__ __launch_bounds__(kBlock * KW, 2) void mmd_gram_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ sq,
                                                             int n, int p, const float* __restrict__ bw_ptr,
                                                             const TileDesc* __restrict__ tiles, int ntiles, float* __restrict__ Wg,
-                                                            int ldw, int wrow0, float* __restrict__ partial, ColmaxJob cj) {
+                                                            int ldw, int wrow0, float* __restrict__ partial, ColmaxJob cj,
+                                                            RbfMults rm = RbfMults{}) {
     using G = GemmTile<GT, GT, GBK * KW, KC, KC, VEC, 0, KW>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     __shared__ float red[16];
@@ -54,11 +63,21 @@ __global__ __launch_bounds__(kBlock * KW, 2) void mmd_gram_kernel(const float* _
     float ksum = 0.f, lsum = 0.f;
 
     float c2 = 0.f, wscale = 0.f;
+    float ck[GEN ? VGAN_RBF_MAX_KERNELS : 1], ik[GEN ? VGAN_RBF_MAX_KERNELS : 1];  // GEN: exp2 factor and 1/scale per kernel
     if constexpr (!CALIB) {
         const float bw = bw_pre;
         c2 = -1.4426950408889634f / (4.f * bw);  // exp(-L/(4bw)) = exp2(L * c2)
         const float sgn = (td.flags & VGAN_TF_NEG) ? -1.f : 1.f;
         wscale = -sgn * 2.f / ((float)n * (float)n * bw);
+        if constexpr (GEN) {
+            wscale = -sgn * 2.f / ((float)n * (float)n);
+#pragma unroll
+            for (int k = 0; k < VGAN_RBF_MAX_KERNELS; ++k) {
+                const float scale = bw * rm.mult[k < rm.nk ? k : 0];
+                ik[k] = 1.f / scale;
+                ck[k] = -1.4426950408889634f / scale;
+            }
+        }
     }
     const bool store = (!CALIB) && (td.flags & VGAN_TF_STORE) && Wg != nullptr;
     const bool mirror = store && (td.flags & VGAN_TF_MIRROR);
@@ -73,11 +92,25 @@ __global__ __launch_bounds__(kBlock * KW, 2) void mmd_gram_kernel(const float* _
         if constexpr (CALIB) {
             lsum += ok ? L : 0.f;
         } else {
-            const float t = __builtin_amdgcn_exp2f(L * c2);  // v_exp_f32
-            const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
-            const float K = ((t + t2) + (t4 + t8)) + t16;
+            float K, w;
+            if constexpr (GEN) {
+                float dk = 0.f;
+                K = 0.f;
+#pragma unroll
+                for (int k = 0; k < VGAN_RBF_MAX_KERNELS; ++k)
+                    if (k < rm.nk) {
+                        const float e = __builtin_amdgcn_exp2f(L * ck[k]);
+                        K += e;
+                        dk = fmaf(e, ik[k], dk);
+                    }
+                w = wscale * dk;
+            } else {
+                const float t = __builtin_amdgcn_exp2f(L * c2);  // v_exp_f32
+                const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+                K = ((t + t2) + (t4 + t8)) + t16;
+                w = wscale * (((0.25f * t + 0.5f * t2) + (t4 + 2.f * t8)) + 4.f * t16);
+            }
             ksum += ok ? K : 0.f;
-            const float w = wscale * (((0.25f * t + 0.5f * t2) + (t4 + 2.f * t8)) + 4.f * t16);
             wv[rr] = w;
             if (store && ok) Wg[(long)(i - wrow0) * ldw + j] = w;
         }
@@ -381,14 +414,14 @@ static void launch_gram_kw(dim3 grid, hipStream_t s, bool vec, int calibrate, co
     dim3 block(kBlock * KW);
     if (calibrate) {
         if (vec)
-            hipLaunchKernelGGL((mmd_gram_kernel<4, true, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+            hipLaunchKernelGGL((mmd_gram_kernel<4, true, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj, RbfMults{});
         else
-            hipLaunchKernelGGL((mmd_gram_kernel<1, true, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+            hipLaunchKernelGGL((mmd_gram_kernel<1, true, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj, RbfMults{});
     } else {
         if (vec)
-            hipLaunchKernelGGL((mmd_gram_kernel<4, false, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+            hipLaunchKernelGGL((mmd_gram_kernel<4, false, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj, RbfMults{});
         else
-            hipLaunchKernelGGL((mmd_gram_kernel<1, false, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+            hipLaunchKernelGGL((mmd_gram_kernel<1, false, KW>), grid, block, 0, s, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj, RbfMults{});
     }
 }
 
@@ -400,6 +433,29 @@ static int launch_gram(const float* Z, int ldz, const float* sq, int n, int p, c
     const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
     dim3 grid(ntiles + extra_blocks);
     launch_gram_kw<kGramKW>(grid, s, vec, calibrate, Z, ldz, sq, n, p, bw, td, ntiles, Wg, ldw, wrow0, partial, cj);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_mmd_gram_general(const float* Z, int ldz, const float* sq, int n, int p, const float* bw, const int32_t* tiles,
+                                     int ntiles, const float* multipliers, int n_kernels, float* Wg, int ldw, int wrow0,
+                                     float* partial, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(Z && sq && tiles && partial && bw && n > 0 && p > 0 && ntiles > 0 && ldz >= p);
+    VGAN_CHECK_ARG(multipliers && n_kernels >= 1 && n_kernels <= VGAN_RBF_MAX_KERNELS && (reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+    RbfMults rm{};
+    rm.nk = n_kernels;
+    for (int k = 0; k < n_kernels; ++k) {
+        VGAN_CHECK_ARG(multipliers[k] > 0.f);
+        rm.mult[k] = multipliers[k];
+    }
+    const TileDesc* td = reinterpret_cast<const TileDesc*>(tiles);
+    const bool vec = (p % 4 == 0) && (ldz % 4 == 0) && aligned16(Z);
+    if (vec)
+        hipLaunchKernelGGL((mmd_gram_kernel<4, false, 1, true>), dim3(ntiles), dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, sq, n, p, bw, td,
+                           ntiles, Wg, ldw, wrow0, partial, ColmaxJob{}, rm);
+    else
+        hipLaunchKernelGGL((mmd_gram_kernel<1, false, 1, true>), dim3(ntiles), dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, sq, n, p, bw, td,
+                           ntiles, Wg, ldw, wrow0, partial, ColmaxJob{}, rm);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vgan_upper_softmax_forward": (_i, [_p, _i, _p, _p, _i, _i, _p]),
     "vgan_mmd_build_tiles": (_i, [_i, _i, _i, _i, _i, _p, _i]),
     "vgan_mmd_gram": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _p, _p]),
+    "vgan_mmd_gram_general": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _p, _p]),
     "vgan_mmd_gram_colmax": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "vgan_mmd_reduce": (_i, [_p, _p, _i, _p, _i, _p]),
     "vgan_mmd_set_bandwidth": (_i, [_p, _i, _p, _p]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "vgan_mse_grad": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
     "vgan_sum_f64": (_i, [_p, _i, ctypes.c_double, _p, _i, _p]),
     "vgan_rbf_kernel_matrix": (_i, [_p, _i, _i, _i, _p, _f, _p, _i, _p]),
+    "vgan_rbf_multi_kernel_matrix": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
     "vgan_rows_dot": (_i, [_p, _i, _p, _i, _p, _i, _i, _p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }

@@ -153,24 +153,98 @@ class Detector(nn.Module):
         return enc_X.view(input.size(0), -1), dec_X.view(input.size(0), -1)
 
 
+class _RBFMatrixFn(torch.autograd.Function):
+    """K = RBF(Z) as an N x N matrix (src/models/Mmd_loss_constrained.py:24-26) with autograd to Z: for an upstream gK,
+    dZ_i = 2 sum_j W_ij (z_i - z_j) with W = (gK + gK^T) * dK/dL -- the backward product of the MMD (vgan_mmd_backward)."""
+
+    @staticmethod
+    def forward(ctx, Z, kernel):
+        ops = default_ops()
+        N, p = Z.shape
+        pp = _round4(p)
+        Zp = torch.zeros(N, pp, dtype=torch.float32, device=Z.device)
+        Zp[:, :p].copy_(Z)
+        sq = torch.empty(N, dtype=torch.float32, device=Z.device)
+        ops.row_sqnorm(Zp, sq, pp)
+        bw = kernel._device_bandwidth(Zp, sq, N, pp)
+        K = torch.empty(N, N, dtype=torch.float32, device=Z.device)
+        dK = torch.empty(N, N, dtype=torch.float32, device=Z.device) if ctx.needs_input_grad[0] else None
+        ops.rbf_multi_kernel_matrix(Zp, sq, bw, kernel.bandwidth_multipliers.tolist(), K, dK)
+        ctx.save_for_backward(Zp, dK)
+        ctx.p = p
+        return K
+
+    @staticmethod
+    def backward(ctx, gK):
+        ops = default_ops()
+        Zp, dK = ctx.saved_tensors
+        N, pp = Zp.shape
+        W = ((gK + gK.t()) * dK).contiguous()
+        out = torch.empty(N, pp, dtype=torch.float32, device=Zp.device)
+        ops.mmd_backward(W, Zp, 0, N, N, pp, None, out)
+        return out[:, :ctx.p], None
+
+
 class RBF(nn.Module):
-    """src/models/Mmd_loss_constrained.py:5-26.  Holds the multipliers and the bandwidth, which is
-    computed on the first call and frozen.  The HIP epilogue evaluates the five kernels with one
-    exp and a squaring chain, which requires the reference's defaults (n_kernels=5, mul_factor=2)."""
+    """src/models/Mmd_loss_constrained.py:5-26.  Holds the multipliers ``mul_factor ** (arange(n_kernels) - n_kernels // 2)``
+    and the bandwidth, which is computed on the first call and frozen.  ``forward(Z)`` returns the N x N kernel matrix like
+    the reference's (for callers of the stand-alone module; MMDLossConstrained never materialises it).  The reference's
+    defaults (n_kernels=5, mul_factor=2) run the fused one-exp squaring chain; any other setting one exp per kernel."""
 
     def __init__(self, n_kernels=5, mul_factor=2.0, bandwidth=None):
         super().__init__()
-        self.n_kernels, self.mul_factor = n_kernels, mul_factor
+        if not (1 <= int(n_kernels) <= 8):
+            raise ValueError(f"RBF: n_kernels must be in 1..8 on the HIP kernels, got {n_kernels}")
+        if not float(mul_factor) > 0.0:
+            raise ValueError(f"RBF: mul_factor must be positive, got {mul_factor}")
+        self.n_kernels, self.mul_factor = int(n_kernels), mul_factor
         self.bandwidth_multipliers = mul_factor ** (torch.arange(n_kernels) - n_kernels // 2)
         self.bandwidth = bandwidth
 
-    def _check_supported(self):
-        if self.n_kernels != 5 or float(self.mul_factor) != 2.0:
-            raise NotImplementedError("the HIP MMD kernel implements the reference's default RBF(n_kernels=5, mul_factor=2.0)")
+    def is_default(self):
+        return self.n_kernels == 5 and float(self.mul_factor) == 2.0
+
+    def _device_bandwidth(self, Zp, sq, N, pp, n_half=None):
+        """The frozen bandwidth as a device scalar [1]; the first call calibrates it from Zp (Mmd_loss_constrained.py:16-22:
+        sum of all squared distances / (N^2 - N)).  N must be even here only when n_half is given (the MMD's stacked operand)."""
+        ops = default_ops()
+        dev = Zp.device
+        if self.bandwidth is None:
+            # sum over all ordered pairs = 2 * (strict upper triangle); the tile table of an n-row "XX" block does exactly that
+            tiles = _tile_cache(ops, N, 0, dev, whole=True)
+            partial = torch.empty(tiles.shape[0], 4, dtype=torch.float32, device=dev)
+            stats = torch.empty(4, dtype=torch.float64, device=dev)
+            bw = torch.empty(1, dtype=torch.float32, device=dev)
+            ops.mmd_gram(Zp, sq, N, pp, None, tiles, True, None, 0, partial)
+            ops.mmd_reduce(partial, tiles, stats, True)
+            stats[3:4].div_(float(N) * N - N)
+            bw.copy_(stats[3:4])
+            self.bandwidth = bw.view(())
+        bw = self.bandwidth
+        if not (torch.is_tensor(bw) and bw.is_cuda and bw.dtype == torch.float32):
+            bw = torch.as_tensor(float(bw), dtype=torch.float32, device=dev)
+        return bw.reshape(1)
 
     def forward(self, X):
-        raise NotImplementedError(
-            "RBF.forward would materialise the N x N kernel matrix; use MMDLossConstrained (fused, never materialised)")
+        if X.dim() != 2:
+            raise ValueError(f"RBF.forward expects a 2-D tensor [N, p], got {tuple(X.shape)}")
+        return _RBFMatrixFn.apply(X.contiguous().float(), self)
+
+
+_TILE_TABLES = {}
+
+
+def _tile_cache(ops, n, grad_mode, dev, whole=False):
+    """Tile tables are a pure function of (n, grad_mode): built and uploaded once per process and device.  whole=True: the
+    table of ONE symmetric n x n block (upper triangle, counted twice off the diagonal) -- used to sum all pair distances."""
+    key = (int(n), int(grad_mode), str(dev), bool(whole))
+    t = _TILE_TABLES.get(key)
+    if t is None:
+        t = ops.build_tiles(n, grad_mode, device=dev)
+        if whole:  # keep the XX tiles of the table only (slot 0): rows/cols in [0, n)
+            t = t[(t[:, 4] & 3) == 0].contiguous()
+        _TILE_TABLES[key] = t
+    return t
 
 
 class _MMDLossFn(torch.autograd.Function):
@@ -190,7 +264,7 @@ class _MMDLossFn(torch.autograd.Function):
         Z[n:, :p].copy_(Y)
         sq = torch.empty(2 * n, dtype=torch.float32, device=dev)
         ops.row_sqnorm(Z, sq, pp)
-        tiles = ops.build_tiles(n, grad_mode, device=dev)
+        tiles = _tile_cache(ops, n, grad_mode, dev)
         partial = torch.empty(tiles.shape[0], 4, dtype=torch.float32, device=dev)
         stats = torch.empty(4, dtype=torch.float64, device=dev)
         if kernel.bandwidth is None:  # first call calibrates and freezes (Mmd_loss_constrained.py:16-20)
@@ -208,7 +282,10 @@ class _MMDLossFn(torch.autograd.Function):
             Wg, wrow0 = torch.empty(n, 2 * n, dtype=torch.float32, device=dev), n
         elif grad_mode == 2:
             Wg, wrow0 = torch.empty(2 * n, 2 * n, dtype=torch.float32, device=dev), 0
-        ops.mmd_gram(Z, sq, n, pp, bw, tiles, False, Wg, wrow0 or 0, partial)
+        if kernel.is_default():
+            ops.mmd_gram(Z, sq, n, pp, bw, tiles, False, Wg, wrow0 or 0, partial)
+        else:
+            ops.mmd_gram_general(Z, sq, n, pp, bw, tiles, kernel.bandwidth_multipliers.tolist(), Wg, wrow0 or 0, partial)
         ops.mmd_reduce(partial, tiles, stats, True)
         Uc = U.detach().contiguous()
         colpart = torch.empty(ops.colmax_chunks(n) * d, dtype=torch.int64, device=dev)
@@ -216,20 +293,24 @@ class _MMDLossFn(torch.autograd.Function):
         ops.colmax(Uc, 0, colpart, colkey, False)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         ops.mmd_loss(stats, colkey, n, d, float(weight), loss)
-        ctx.save_for_backward(Z, colkey)
-        ctx.Wg, ctx.wrow0, ctx.dims, ctx.weight, ctx.grad_mode = Wg, wrow0, (n, p, pp, d), float(weight), grad_mode
+        if Wg is not None:
+            ctx.save_for_backward(Z, colkey, Wg)
+        else:
+            ctx.save_for_backward(Z, colkey)
+        ctx.wrow0, ctx.dims, ctx.weight, ctx.grad_mode = wrow0, (n, p, pp, d), float(weight), grad_mode
         return loss.view(())
 
     @staticmethod
     def backward(ctx, gl):
         ops = default_ops()
-        Z, colkey = ctx.saved_tensors
+        Z, colkey = ctx.saved_tensors[:2]
         n, p, pp, d = ctx.dims
         dX = dY = dU = None
         if ctx.grad_mode:
+            Wg = ctx.saved_tensors[2]
             nr = n if ctx.grad_mode == 1 else 2 * n
             out = torch.empty(nr, pp, dtype=torch.float32, device=Z.device)
-            ops.mmd_backward(ctx.Wg, Z, ctx.wrow0, nr, 2 * n, pp, None, out)
+            ops.mmd_backward(Wg, Z, ctx.wrow0, nr, 2 * n, pp, None, out)
             out = out[:, :p] * gl
             if ctx.grad_mode == 1:
                 dY = out
@@ -254,7 +335,13 @@ class MMDLossConstrained(nn.Module):
         self.weight = weight
 
     def forward(self, X, Y, U):
-        self.kernel._check_supported()
+        # the reference takes block means over arbitrary row counts of X and Y (Mmd_loss_constrained.py:46-49); every caller in
+        # the reference passes Y = f(U * X), i.e. equal shapes, and the tile tables of this build assume that
+        if X.dim() != 2 or Y.shape != X.shape:
+            raise ValueError(f"MMDLossConstrained: X and Y must be 2-D with equal shapes on this build, got {tuple(X.shape)} and "
+                             f"{tuple(Y.shape)}")
+        if U.dim() != 2 or U.shape[0] != X.shape[0]:
+            raise ValueError(f"MMDLossConstrained: U must be [n, d] with n = {X.shape[0]} rows, got {tuple(U.shape)}")
         out = _MMDLossFn.apply(X.contiguous().float(), Y.contiguous().float(), U, self.weight, self.kernel)
         self.bandwidth = self.kernel.bandwidth
         self.bandwidth_multipliers = self.kernel.bandwidth_multipliers

@@ -186,13 +186,38 @@ class HipOps:
 
     def mmd_gram(self, Z, sq, n, p, bw, tiles, calibrate, Wg, wrow0, partial):
         _mat(Z, "Z")
-        assert Z.shape[0] >= 2 * n and tiles.dtype == torch.int32 and tiles.is_contiguous()
+        assert (calibrate or Z.shape[0] >= 2 * n) and tiles.dtype == torch.int32 and tiles.is_contiguous()  # (calibration: the table bounds the rows)
         ntiles = tiles.shape[0]
         assert partial.numel() >= 4 * ntiles
         ldw = Wg.stride(0) if Wg is not None else 0
         _lib.check(self.lib.vgan_mmd_gram(_ptr(Z), Z.stride(0), _ptr(sq), int(n), int(p), _ptr(bw), _ptr(tiles), ntiles,
                                           int(bool(calibrate)), _ptr(Wg), ldw, int(wrow0), _ptr(partial), self._stream()),
                    "vgan_mmd_gram")
+
+    @staticmethod
+    def _mults(multipliers):
+        vals = [float(v) for v in multipliers]
+        return (ctypes.c_float * len(vals))(*vals), len(vals)
+
+    def mmd_gram_general(self, Z, sq, n, p, bw, tiles, multipliers, Wg, wrow0, partial):
+        """mmd_gram (no calibration) for RBF(n_kernels, mul_factor) other than the reference's defaults: `multipliers` is the
+        host list mul_factor ** (k - n_kernels // 2)."""
+        _mat(Z, "Z")
+        ntiles = tiles.shape[0]
+        assert partial.numel() >= 4 * ntiles
+        arr, nk = self._mults(multipliers)
+        ldw = Wg.stride(0) if Wg is not None else 0
+        _lib.check(self.lib.vgan_mmd_gram_general(_ptr(Z), Z.stride(0), _ptr(sq), int(n), int(p), _ptr(bw), _ptr(tiles), ntiles, arr, nk,
+                                                  _ptr(Wg), ldw, int(wrow0), _ptr(partial), self._stream()), "vgan_mmd_gram_general")
+
+    def rbf_multi_kernel_matrix(self, Z, sq, bw, multipliers, K, dK=None):
+        """RBF.forward: K [m, m] = sum_k exp(-|z_i - z_j|^2 / (bw * multipliers[k])); dK (optional) = dK/dL."""
+        _mat(Z, "Z"), _mat(K, "K")
+        m, p = Z.shape
+        arr, nk = self._mults(multipliers)
+        _lib.check(self.lib.vgan_rbf_multi_kernel_matrix(_ptr(Z), Z.stride(0), m, p, _ptr(sq), _ptr(bw), arr, nk, _ptr(K), K.stride(0),
+                                                         _ptr(dK), dK.stride(0) if dK is not None else 0, self._stream()),
+                   "vgan_rbf_multi_kernel_matrix")
 
     def mmd_gram_colmax(self, Z, sq, n, p, bw, tiles, Wg, wrow0, partial, S, row_offset, colpart, from_softmax=True):
         """mmd_gram (no calibration) + colmax_partial(S) in one launch."""
