@@ -325,6 +325,23 @@ int vgan_mse_grad(const float* target, int ldt, const float* pred, int ldp, int 
 int vgan_sum_f64(const double* in, int count, double scale, float* out, int accumulate, vgan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input pipeline / sampling post-processing on the device  
+ * vgan_shuffle_epoch: perm[i] = pi_{seed,epoch}(i) for i < count, pi a pseudo-random permutation of [0, train_size)
+ * evaluated per element (balanced Feistel network + cycle walking): the shuffled drop_last batches of one epoch
+ * (DataLoader(shuffle=True, drop_last=True), src/vgan.py:578-584) without a host draw, a sort or a copy.  It is NOT torch's
+ * randperm stream: parity runs keep the host draw.  vgan_shuffle_index evaluates the same permutation on the host.
+ * vgan_mask_unique: np.unique(masks, axis=0, return_counts=True) of approx_subspace_dist (src/vgan.py:372-382) for a
+ * boolean (uint8) mask matrix [n, d]: out_row[r] = index of the first sampled row holding the r-th distinct mask in
+ * numpy's lexicographic order, out_count[r] = its multiplicity; entries r >= #distinct are left untouched (pre-zero
+ * out_count).  keys: workspace [n * ceil(d/64)] u64, work: [2n] i32.
+ * ------------------------------------------------------------------------------------------- */
+int vgan_shuffle_epoch(int32_t* perm, int64_t count, int64_t train_size, uint64_t seed, uint64_t epoch,
+                       vgan_stream_t stream);
+int64_t vgan_shuffle_index(int64_t i, int64_t train_size, uint64_t seed, uint64_t epoch);
+int vgan_mask_unique(const uint8_t* masks, int ldm, int n, int d, uint64_t* keys, int32_t* work,
+                     int32_t* out_row, int32_t* out_count, vgan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Myopicity two-sample test  (check_if_myopic, src/vgan.py:384-431 -> torch-two-sample's MMDStatistic
  * with ret_matrix=True and its permutation p-value; that dependency is absent and unpinned, the algorithm
  * is restated in oracle/vgan_oracle.py: PARITY UNPINNED against the dependency).

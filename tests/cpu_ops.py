@@ -366,6 +366,19 @@ class CpuOps:
         a, b = _np(A).astype(np.float64), _np(B).astype(np.float64)
         out[:a.shape[0]].copy_(torch.as_tensor((a * (b.reshape(1, -1) if broadcast_b else b)).sum(1)))
 
+    # ---- input pipeline (host evaluation of the library's own permutation: same numbers as the device kernel)
+    def shuffle_epoch(self, perm, train_size, seed, epoch):
+        flat = perm.view(-1)
+        for i in range(flat.numel()):
+            flat[i] = self.shuffle_index(i, train_size, seed, epoch)
+
+    def shuffle_index(self, i, train_size, seed, epoch):
+        return int(self.lib.vgan_shuffle_index(int(i), int(train_size), int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch) & 0xFFFFFFFFFFFFFFFF))
+
+    def mask_unique(self, masks):
+        u, c = np.unique(masks.numpy(), axis=0, return_counts=True)
+        return torch.as_tensor(u), torch.as_tensor(c)
+
     # ---- optimiser / noise
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         if nslabs > 1:

@@ -21,6 +21,8 @@ alone, so they stay valid across torch versions.
                    per-step loss, final params, generate_subspaces(500) masks
   f4_kl_c1.npz     VGAN.fit (kernel learning) 12 epochs at c1: both loss histories + masks
   f5_c3_scalars.npz  c3 (d=784, n=1024) single step, fp64 + fp32 scalars on documented inputs
+  f6_ref_generator_c1.pt, f6_ref_run.npz   a run folder written by the reference's fit(path_to_directory=...): its saved
+                   generator state_dict, the masks the reference samples from it after load_models, its CSV texts
 """
 import os
 import sys
@@ -29,8 +31,10 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 sys.dont_write_bytecode = True
+# the reference's `src` is a namespace package (no __init__.py) while this repository's `src` is a regular one, which would
+# win wherever it sits on sys.path: the repository root is only added AFTER the reference's modules have been imported
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
 sys.path.insert(0, "/root/reference")
-sys.path.insert(1, REPO)
 sys.modules.setdefault("torch_two_sample", types.ModuleType("torch_two_sample"))
 
 import numpy as np  # noqa: E402
@@ -42,6 +46,7 @@ import src.vgan as ref_vgan  # noqa: E402  (reference)
 
 assert ref_vgan.__file__.startswith("/root/reference"), ref_vgan.__file__
 
+sys.path.insert(1, REPO)
 from oracle import vgan_oracle as orc  # noqa: E402  (only for the documented synthetic inputs)
 
 torch.set_num_threads(8)
@@ -292,7 +297,40 @@ def make_f5():
     print("f5", out["loss_f64"], out["loss_f32"], out["bw_f64"], out["nsel_f64"])
 
 
+# ---------------------------------------------------------------------------- F6
+def make_f6():
+    """A run folder written by the REFERENCE (fit with path_to_directory, src/vgan.py:626-635): its generator_0.pt (a plain
+    state_dict, loadable with weights_only=True) is kept as a fixture together with what the reference's own load_models +
+    generate_subspaces return for it, and the text of params.csv / generator_loss_0.csv (the file layout to reproduce)."""
+    import shutil
+    import tempfile
+    data = orc.synthetic_dataset("c1", rows=640)
+    reset_shared_rbf()
+    with tempfile.TemporaryDirectory() as tmp:
+        run = os.path.join(tmp, "run")
+        model = ref_vgan.VGAN_no_kl(batch_size=128, epochs=3, seed=5, path_to_directory=run)
+        model.device = torch.device("cpu")
+        model.fit(data)
+        shutil.copyfile(os.path.join(run, "models", "generator_0.pt"), os.path.join(HERE, "f6_ref_generator_c1.pt"))
+        fresh = ref_vgan.VGAN_no_kl(seed=5)
+        fresh.device = torch.device("cpu")
+        fresh.load_models(os.path.join(run, "models", "generator_0.pt"), ndims=20, device="cpu")
+        fresh._latent_size = 1  # set by fit() in the reference; load_models alone leaves it unset (src/vgan.py:511-527)
+        masks = t2n(fresh.generate_subspaces(64))
+        torch.manual_seed(5)  # what generate_subspaces drew (src/vgan.py:641-644), recorded as an array
+        mask_noise = torch.Tensor(64, 1).normal_()
+        assert np.array_equal(t2n(fresh.generator(mask_noise) >= 1 / 20), masks)
+        out = dict(masks=masks, mask_noise=t2n(mask_noise), files=np.array(sorted(os.listdir(run))), model_files=np.array(sorted(os.listdir(os.path.join(run, "models")))),
+                   params_csv=np.array(open(os.path.join(run, "params.csv")).read()),
+                   loss_csv=np.array(open(os.path.join(run, "train_history", "generator_loss_0.csv")).read()),
+                   epoch_losses=np.array(model.train_history["generator_loss"]))
+        for i, q in enumerate(model.generator.parameters()):
+            out[f"param_{i}"] = t2n(q)
+    np.savez_compressed(os.path.join(HERE, "f6_ref_run.npz"), **out)
+    print("f6", out["files"], out["model_files"], str(out["params_csv"])[:200], masks.sum(0))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
     for w in which:
         globals()[f"make_{w}"]()

@@ -520,6 +520,91 @@ def test_c2_fit_end_to_end_device_noise():
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
 
 
+def test_two_fits_in_one_process_share_the_bandwidth():
+    """The reference's shared-RBF quirk (Mmd_loss_constrained.py:35: ONE default RBF per process): a second fit finds the
+    bandwidth already frozen by the first.  Its engine then never calibrates: its first step must run eagerly (first-ever
+    launches of the bf16x3 kernels, the one-off noise draw) and only the later ones replay a captured graph."""
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    a = VGAN_no_kl(batch_size=128, epochs=2, seed=1)
+    a.verbose = False
+    a.fit(orc.synthetic_dataset("c1", rows=512))
+    bw = float(a.bandwidth)
+    rng = np.random.default_rng(3)
+    b = VGAN_no_kl(batch_size=1024, epochs=2, seed=2)   # 2 n d >= 2^20: the engine picks the split-bf16 kernels
+    b.verbose = False
+    b.fit(rng.normal(size=(3072, 512)).astype(np.float32))
+    assert b._engine.precision == "bf16x3" and b._engine.graph is not None and b._engine.steps_done == 6
+    assert float(b.bandwidth) == bw and float(b._engine.bw) == bw
+    assert np.isfinite(b.train_history["generator_loss"]).all()
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
+def test_device_shuffle_and_mask_unique(ops):
+    """SURVEY 8f rank 4 on the device: vgan_shuffle_epoch equals the host evaluation of the same counter-based permutation
+    (a bijection: distinct rows, different every epoch) and a fit driven by it trains; vgan_mask_unique equals
+    np.unique(masks, axis=0, return_counts=True) -- rows, order and counts -- which approx_subspace_dist now uses."""
+    for N, count in ((16384, 16384), (5001, 4096), (3, 2)):
+        perm = torch.full((count,), -1, dtype=torch.int32, device="cuda")
+        ops.shuffle_epoch(perm, N, 777, 5)
+        got = host(perm)
+        assert got.tolist() == [ops.shuffle_index(i, N, 777, 5) for i in range(count)]
+        assert len(set(got.tolist())) == count and got.min() >= 0 and got.max() < N
+    rng = np.random.default_rng(12)
+    for n, d in ((1, 20), (500, 20), (500, 64), (777, 65), (1000, 784)):
+        base = rng.random((max(n // 7, 1), d)) < 0.4
+        masks = base[rng.integers(0, base.shape[0], size=n)]
+        masks[rng.integers(0, n, size=n // 10), rng.integers(0, d, size=n // 10)] ^= True
+        u, c = ops.mask_unique(torch.as_tensor(masks).cuda())
+        ur, cr = np.unique(masks, axis=0, return_counts=True)
+        assert np.array_equal(host(u), ur) and np.array_equal(c.numpy(), cr), (n, d)
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    model = VGAN_no_kl(batch_size=128, epochs=4, seed=3)
+    model.verbose, model.shuffle_source = False, "device"
+    model.fit(orc.synthetic_dataset("c1", rows=700))
+    assert np.isfinite(model.train_history["generator_loss"]).all()
+    perm = host(model._engine.perm)
+    assert perm.shape == (5, 128) and len(set(perm.ravel().tolist())) == 640
+    model.approx_subspace_dist(subspace_count=300)
+    ur, cr = np.unique(host(model.generate_subspaces(300)), axis=0, return_counts=True)
+    assert np.array_equal(model.subspaces, ur) and np.allclose(model.proba, cr / cr.sum())
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
+def test_reference_saved_checkpoint_and_run_folder_interchange():
+    """f6: a run folder written by the REFERENCE.  Its generator_0.pt goes through this build's load_models (weights-only)
+    and generate_subspaces returns the masks the reference itself sampled from it; a fit of this build with the same
+    hyper-parameters writes the same files, the same params.csv text and a generator_loss CSV of the same shape."""
+    import tempfile
+    from conftest import REPO
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    g = load_golden("f6_ref_run.npz")
+    m = VGAN_no_kl(seed=5)
+    m.load_models(os.path.join(REPO, "tests", "golden", "f6_ref_generator_c1.pt"), ndims=20)
+    masks = m.generate_subspaces(64)
+    assert np.array_equal(host(masks), g["masks"])
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    with tempfile.TemporaryDirectory() as tmp:
+        run = os.path.join(tmp, "run")
+        model = VGAN_no_kl(batch_size=128, epochs=3, seed=5, path_to_directory=run)
+        model.verbose = False
+        model.noise_source = "host"
+        model.fit(orc.synthetic_dataset("c1", rows=640))
+        assert sorted(os.listdir(run)) == list(g["files"]) and sorted(os.listdir(os.path.join(run, "models"))) == list(g["model_files"])
+        assert open(os.path.join(run, "params.csv")).read() == str(g["params_csv"])
+        ours = np.loadtxt(os.path.join(run, "train_history", "generator_loss_0.csv"), ndmin=1)
+        ref = np.array([float(v) for v in str(g["loss_csv"]).split()])
+        np.testing.assert_allclose(ours, ref, rtol=0, atol=1e-4)      # same seed, same RNG order: the reference's own epoch losses
+        sd = torch.load(os.path.join(run, "models", "generator_0.pt"), weights_only=True)
+        for i, v in enumerate(sd.values()):
+            np.testing.assert_allclose(host(v), g[f"param_{i}"], rtol=0, atol=2e-5)
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
 # ------------------------------------------------------------------------------ split-bf16 ("bf16x3") MMD mode
 def test_bf3_prepare_and_kernels_vs_fp64(ops):
     n, d = 1024, 784

@@ -125,6 +125,36 @@ def test_batch_size_clamp_and_history_shape():
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
 
 
+def test_device_shuffle_is_a_permutation_and_drives_fit():
+    """vgan_shuffle_epoch's counter-based permutation (host evaluation, vgan_shuffle_index): a bijection of [0, N) for sizes
+    that are and are not powers of four, different per epoch and per seed; a fit with shuffle_source='device' consumes it
+    (every epoch's batches are disjoint rows of the data set) and draws nothing from torch's generator for the shuffle."""
+    ops = CpuOps()
+    for N in (1, 2, 7, 64, 1000, 4096, 5001):
+        p = [ops.shuffle_index(i, N, 777, 3) for i in range(N)]
+        assert sorted(p) == list(range(N)), N
+    a = [ops.shuffle_index(i, 5001, 777, 3) for i in range(5001)]
+    b = [ops.shuffle_index(i, 5001, 777, 4) for i in range(5001)]
+    c = [ops.shuffle_index(i, 5001, 778, 3) for i in range(5001)]
+    assert sum(x == y for x, y in zip(a, b)) < 20 and sum(x == y for x, y in zip(a, c)) < 20
+    assert abs(np.corrcoef(a, np.arange(5001))[0, 1]) < 0.05
+    assert ops.shuffle_index(5, 5, 1, 1) == -1 and ops.shuffle_index(-1, 5, 1, 1) == -1
+
+    from src.vgan import VGAN_no_kl
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+    X = orc.synthetic_dataset("c1", rows=300)
+    model = VGAN_no_kl(batch_size=128, epochs=2, seed=9)
+    model._ops_override, model.device, model.verbose, model.noise_source = ops, torch.device("cpu"), False, "host"
+    model.shuffle_source = "device"
+    model.fit(X)
+    perm = model._engine.perm.numpy()                     # the last epoch's table: 2 batches of 128 distinct rows of 300
+    assert perm.shape == (2, 128) and len(set(perm.ravel().tolist())) == 256 and perm.min() >= 0 and perm.max() < 300
+    assert perm.ravel().tolist() == [ops.shuffle_index(i, 300, 9, 1) for i in range(256)]
+    assert np.isfinite(model.train_history["generator_loss"]).all()
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
 def _myopic_reference(model, data, bandwidths, count, n_perm):
     """p-values of oracle.two_sample_pvalue on exactly the samples / permutations check_if_myopic draws."""
     x = np.asarray(data, dtype=np.float64)

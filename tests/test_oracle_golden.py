@@ -121,3 +121,20 @@ def test_torch_port_matches_reference_step():
         assert abs(loss - float(g[f"loss{step}"])) < 1e-6
         for i in range(8):
             np.testing.assert_allclose(tr.params[i].detach().numpy(), g[f"param{step + 1}_{i}"], rtol=0, atol=1e-7)
+
+
+def test_f6_reference_saved_checkpoint_loads_weights_only():
+    """The generator_0.pt a reference fit wrote (src/vgan.py:626-635) is a plain state_dict: keys main.{0..3}.{weight,bias},
+    loadable with weights_only=True; the oracle's generator on the recorded noise reproduces the masks the reference sampled
+    from it after its own load_models (src/vgan.py:511-527, :639-647)."""
+    import os
+    from conftest import REPO
+    g = load_golden("f6_ref_run.npz")
+    sd = torch.load(os.path.join(REPO, "tests", "golden", "f6_ref_generator_c1.pt"), map_location="cpu", weights_only=True)
+    assert list(sd) == [f"main.{k}.{w}" for k in range(4) for w in ("weight", "bias")]
+    params = [v.numpy() for v in sd.values()]
+    for i, q in enumerate(params):
+        assert np.array_equal(q, g[f"param_{i}"])
+    masks = orc.NoKLTrainer(params).masks(g["mask_noise"])
+    assert np.array_equal(masks, g["masks"])
+    assert list(g["files"]) == ["models", "params.csv", "train_history", "train_history.pdf"]

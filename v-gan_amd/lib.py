@@ -70,6 +70,9 @@ SIGNATURES = {
     "vgan_rbf_kernel_matrix": (_i, [_p, _i, _i, _i, _p, _f, _p, _i, _p]),
     "vgan_rbf_multi_kernel_matrix": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
     "vgan_rows_dot": (_i, [_p, _i, _p, _i, _p, _i, _i, _p]),
+    "vgan_shuffle_epoch": (_i, [_p, _i64, _i64, _u64, _u64, _p]),
+    "vgan_shuffle_index": (_i64, [_i64, _i64, _u64, _u64]),
+    "vgan_mask_unique": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 

@@ -335,6 +335,33 @@ class HipOps:
         ldb = 0 if broadcast_b else B.stride(0)
         _lib.check(self.lib.vgan_rows_dot(_ptr(A), A.stride(0), _ptr(B), ldb, _ptr(out), rows, cols, self._stream()), "vgan_rows_dot")
 
+    # ---- input pipeline / sampling post-processing on the device ------------------------------------
+    def shuffle_epoch(self, perm, train_size, seed, epoch):
+        """perm (int32, any shape, contiguous): the first perm.numel() entries of a pseudo-random permutation of
+        [0, train_size) keyed by (seed, epoch) -- one epoch of shuffled drop_last batches, produced on the device."""
+        _vec(perm, "perm", torch.int32)
+        _lib.check(self.lib.vgan_shuffle_epoch(_ptr(perm), perm.numel(), int(train_size), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                               int(epoch) & 0xFFFFFFFFFFFFFFFF, self._stream()), "vgan_shuffle_epoch")
+
+    def shuffle_index(self, i, train_size, seed, epoch):
+        return int(self.lib.vgan_shuffle_index(int(i), int(train_size), int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch) & 0xFFFFFFFFFFFFFFFF))
+
+    def mask_unique(self, masks):
+        """masks: bool [n, d] on the device -> (unique rows [m, d] bool in numpy's np.unique(axis=0) order, counts [m] int64)."""
+        assert masks.is_cuda and masks.dtype == torch.bool and masks.dim() == 2
+        m8 = masks.contiguous().view(torch.uint8)
+        n, d = m8.shape
+        dev = masks.device
+        keys = torch.empty(n * ((d + 63) // 64), dtype=torch.int64, device=dev)
+        work = torch.empty(2 * n, dtype=torch.int32, device=dev)
+        out_row = torch.zeros(n, dtype=torch.int32, device=dev)
+        out_count = torch.zeros(n, dtype=torch.int32, device=dev)
+        _lib.check(self.lib.vgan_mask_unique(_ptr(m8), m8.stride(0), n, d, _ptr(keys), _ptr(work), _ptr(out_row), _ptr(out_count),
+                                             self._stream()), "vgan_mask_unique")
+        cnt = out_count.cpu()
+        m = int((cnt > 0).sum())
+        return masks[out_row[:m].long()], cnt[:m].to(torch.int64)
+
     # ---- optimiser / noise / misc ----------------------------------------------------------------
     def adadelta_step(self, p, g, sq, acc, lr, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0, nslabs=1, slab_stride=0):
         """nslabs > 1: `g` is slab 0 of split-K gradient slabs `slab_stride` apart, summed inside the kernel."""
@@ -369,9 +396,11 @@ class HipOps:
     def homogeneous_pack(self, layers, unpack=False):
         """layers: [(W [out,in], b [out], P [>=out+1, >=in+1]) ...].  pack: P = [[W, b],[0, 1]]; unpack: (W, b) <- P.
         One launch for all layers; the device-side pointer table is built once per distinct layer set."""
-        key = tuple((W.data_ptr(), b.data_ptr(), P.data_ptr()) for W, b, P in layers)
+        key = tuple((W.data_ptr(), tuple(W.shape), W.stride(0), b.data_ptr(), P.data_ptr(), tuple(P.shape), P.stride(0)) for W, b, P in layers)
         cache = self.__dict__.setdefault("_pack_tables", {})
         if key not in cache:
+            if len(cache) >= 16:  # a handful of live engines at most: drop the oldest table instead of growing without bound
+                cache.pop(next(iter(cache)))
             rows = []
             for W, b, P in layers:
                 _mat(W, "W"), _vec(b, "b"), _mat(P, "P")

@@ -243,6 +243,11 @@ class NoKLStepEngine:
         """idx: [batches_per_epoch, n] integer tensor of shuffled row indices (DataLoader order)."""
         self.perm.copy_(idx.to(dtype=torch.int32), non_blocking=True)
 
+    def shuffle_epoch(self, epoch):
+        """This epoch's shuffled drop_last batches from the device-side counter-based permutation (vgan_shuffle_epoch), keyed
+        by (seed, epoch): identical on every rank, no host draw and no H2D copy."""
+        self.ops.shuffle_epoch(self.perm, self.data.shape[0], self.seed, int(epoch))
+
     def set_bandwidth(self, value):
         self.bw.fill_(float(value))
         self.has_bw = True
@@ -400,19 +405,34 @@ class NoKLStepEngine:
             self._forward()
             self._calibrate()
             self._loss_backward_update()
-        elif self.use_graph:
+        elif self.use_graph and self.steps_done > 0:
             if self.graph is None:
                 self._capture()
-            self.graph.replay()
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step_body()
         else:
+            # eager: graphs off, or the very first step of an engine whose bandwidth was handed over (a second fit in one
+            # process: the shared-RBF quirk) -- its first-ever launches and the one-off noise draw stay outside the capture
             self._step_body()
         self.steps_done += 1
 
     def _capture(self):
+        """Captures one step into a HIP graph.  If the capture fails (e.g. a collective that cannot be captured on this
+        stack) the engine keeps running the same launches eagerly, in this process."""
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._step_body()
+        try:
+            with torch.cuda.graph(g):
+                self._step_body()
+        except Exception as e:  # noqa: BLE001 -- any capture failure means "no graph", never "no training"
+            import warnings
+            warnings.warn(f"vgan_amd: HIP-graph capture of the training step failed ({type(e).__name__}: {e}); running eager launches")
+            torch.cuda.synchronize()
+            self.use_graph = False
+            self.graph = None
+            return
         # capture does not execute: the step that triggered it still has to run once
         self.graph = g
 

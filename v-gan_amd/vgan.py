@@ -70,55 +70,59 @@ def _dist_info():
 
 
 class _RunFolder:
-    """model_snapshot / get_params / plot: the reference's run-folder side outputs (src/vgan.py:80-140,
-    456-509).  Plain host code, same file names and CSV layout."""
+    """Side outputs and sampling helpers shared by both model classes: the run folder a fit leaves behind
+    (<dir>/models/generator_<k>.pt, <dir>/train_history/generator_loss_<k>.csv, <dir>/params.csv, <dir>/train_history.pdf --
+    the layout of src/vgan.py:111-140, 339-350, 626-635, pinned by fixture f6), load_models, generate_subspaces and
+    approx_subspace_dist.  Host code except for the generator forward and the unique-count, which run on the GPU."""
 
-    def _plot_loss(self, path_to_directory, with_detector):
+    def _write_loss_plot(self, folder):
+        """train_history.pdf: one curve per recorded loss history (generator; detector too for VGAN)."""
         try:
             import matplotlib
             matplotlib.use("Agg")
-            import matplotlib.pyplot as plt
-        except Exception:  # plotting is a convenience; training must not depend on it
+            from matplotlib import pyplot
+        except Exception:  # a missing plotting stack must not fail a training run
             return
-        generator_y = self.train_history["generator_loss"]
-        x = np.linspace(1, len(generator_y), len(generator_y))
-        fig, ax = plt.subplots()
-        ax.plot(x, generator_y, color="cornflowerblue", label="Generator loss", linewidth=2)
-        if with_detector:
-            ax.plot(x, self.train_history["detector_loss"], color="black", label="Detector loss", linewidth=2)
-        plt.xlabel("Epoch")
-        plt.ylabel("Loss")
-        ax.legend(loc="upper right")
-        plt.savefig(Path(path_to_directory) / "train_history.pdf", format="pdf", dpi=1200)
-        plt.close(fig)
+        curves = [("generator_loss", "Generator loss", "cornflowerblue")]
+        if hasattr(self, "lr_D"):
+            curves.append(("detector_loss", "Detector loss", "black"))
+        figure, axes = pyplot.subplots()
+        for key, label, colour in curves:
+            values = list(self.train_history[key])
+            axes.plot(range(1, len(values) + 1), values, label=label, color=colour, linewidth=2)
+        axes.set_xlabel("Epoch")
+        axes.set_ylabel("Loss")
+        axes.legend(loc="upper right")
+        figure.savefig(Path(folder) / "train_history.pdf", format="pdf", dpi=1200)
+        pyplot.close(figure)
 
     def model_snapshot(self, path_to_directory=None, run_number=0, show=False):
+        """Writes this run's loss history and hyper-parameters into the run folder (``show`` is accepted and ignored, as in
+        the reference, which deprecated it)."""
         import pandas as pd
-        if path_to_directory is None:
-            path_to_directory = self.path_to_directory
-        path_to_directory = Path(path_to_directory)
-        os.makedirs(path_to_directory / "train_history", exist_ok=True)
-        pd.DataFrame(self.train_history["generator_loss"]).to_csv(
-            path_to_directory / "train_history" / f"generator_loss_{run_number}.csv", header=False, index=False)
-        if not os.path.isfile(path_to_directory / "params.csv"):
-            pd.DataFrame(self.get_params(), [0]).to_csv(path_to_directory / "params.csv")
-        else:
-            params = pd.read_csv(path_to_directory / "params.csv", index_col=0)
-            params_new = pd.DataFrame(self.get_params(), [run_number])
-            params = params.reindex(params.index.union(params_new.index))
-            params.update(params_new)
-            params.to_csv(path_to_directory / "params.csv")
-        self._plot_loss(path_to_directory, with_detector=hasattr(self, "lr_D"))
+        folder = Path(self.path_to_directory if path_to_directory is None else path_to_directory)
+        (folder / "train_history").mkdir(parents=True, exist_ok=True)
+        history = pd.Series(list(self.train_history["generator_loss"]))
+        history.to_csv(folder / "train_history" / f"generator_loss_{run_number}.csv", header=False, index=False)
+        # params.csv: one row per run number; an existing file keeps its other rows, this run's row is added or replaced
+        table_path = folder / "params.csv"
+        table = pd.read_csv(table_path, index_col=0) if table_path.is_file() else pd.DataFrame()
+        row = pd.DataFrame.from_dict({run_number: self.get_params()}, orient="index")
+        table = row.combine_first(table)[list(row.columns) + [c for c in table.columns if c not in row.columns]]
+        table.sort_index().to_csv(table_path)
+        self._write_loss_plot(folder)
 
     def load_models(self, path_to_generator, ndims, device=None):
-        """src/vgan.py:142-158 / 511-527: restore a generator for sampling (state_dict keys main.N.*)."""
-        if device is None:
-            device = self.device
-        self.generator = Generator_big(img_size=ndims, latent_size=max(int(ndims / 16), 1)).to(device)
-        self.generator.load_state_dict(torch.load(path_to_generator, map_location=device, weights_only=True))
-        self.generator.eval()
+        """src/vgan.py:142-158 / 511-527: restore a generator for sampling.  The file is a plain state_dict (keys main.N.weight /
+        main.N.bias, as the reference writes it) and is read with ``weights_only=True``."""
+        device = self.device if device is None else device
+        latent = max(int(ndims / 16), 1)
+        generator = Generator_big(img_size=ndims, latent_size=latent).to(device)
+        generator.load_state_dict(torch.load(path_to_generator, map_location=device, weights_only=True))
+        generator.eval()
+        self.generator = generator
+        self._latent_size = latent
         self.generator_optimizer = f"Loaded Model from {path_to_generator} with {ndims} dimensions in the latent space"
-        self._latent_size = max(int(ndims / 16), 1)
 
     def _ops(self):
         return getattr(self, "_ops_override", None) or default_ops()
@@ -150,14 +154,17 @@ class _RunFolder:
         return self.generate_subspaces(nsubs)
 
     def approx_subspace_dist(self, subspace_count=500, add_leftover_features=False):
-        """src/vgan.py:372-382 / 649-659."""
-        u = self.generate_subspaces(subspace_count)
-        unique_subspaces, proba = np.unique(u.to("cpu").numpy(), axis=0, return_counts=True)
-        if (unique_subspaces.sum(axis=0) < 1).sum() != 0 and add_leftover_features:
-            unique_subspaces = np.append(unique_subspaces, [unique_subspaces.sum(axis=0) < 1], axis=0)
-            proba = np.append(proba / proba.sum(), 1)
-        self.subspaces = unique_subspaces
-        self.proba = proba / proba.sum()
+        """src/vgan.py:372-382 / 649-659: the distinct sampled subspaces (rows in np.unique's order) and their empirical
+        probabilities.  The sort-free unique-count runs on the GPU (vgan_mask_unique); only the distinct rows come back."""
+        masks = self.generate_subspaces(subspace_count)
+        distinct, counts = self._ops().mask_unique(masks)
+        distinct, weights = distinct.to("cpu").numpy(), counts.to("cpu").numpy().astype(np.float64)
+        never_selected = ~distinct.any(axis=0)
+        if add_leftover_features and never_selected.any():  # one more "subspace" holding every feature no sample selected
+            distinct = np.vstack([distinct, never_selected[None, :]])
+            weights = np.append(weights / weights.sum(), 1.0)
+        self.subspaces = distinct
+        self.proba = weights / weights.sum()
 
     def check_if_myopic(self, x_data, bandwidth=0.01, count=500, n_permutations=1000):
         """src/vgan.py:384-431: two-sample (MMD, permutation) test of P(x) against P(u * x + mean(x) * ~u), once per given
@@ -252,6 +259,7 @@ class VGAN_no_kl(_RunFolder):
         self.device = _device()
         # build-specific knobs (not constructor arguments, so the reference signature is unchanged)
         self.noise_source = "device"   # "device": Philox on the GPU; "host": torch CPU generator (reference CPU-path RNG order)
+        self.shuffle_source = "host"   # "host": the DataLoader's own draws (reference RNG order); "device": vgan_shuffle_epoch
         self.use_graph = True
         self.mmd_precision = None      # None: VGAN_MMD_PRECISION or "auto" (see NoKLStepEngine); "fp32" | "bf16x3"
         self.verbose = True
@@ -307,7 +315,10 @@ class VGAN_no_kl(_RunFolder):
         for epoch in range(epochs):
             if self.verbose:
                 print(f"\rEpoch {epoch} of {epochs}")
-            engine.set_epoch_batches(epoch_batches(train_size, self.batch_size))
+            if self.shuffle_source == "device":   # counter-based permutation evaluated on the GPU: no host draw, no copy
+                engine.shuffle_epoch(epoch)
+            else:
+                engine.set_epoch_batches(epoch_batches(train_size, self.batch_size))
             if self.noise_source == "host":
                 noise_tensor = torch.Tensor(self.batch_size, latent_size)  # src/vgan.py:594
             for _ in range(batches_per_epoch):
@@ -329,8 +340,8 @@ class VGAN_no_kl(_RunFolder):
 
 class VGAN(_RunFolder):
     """V-GAN with kernel learning (reference: src/vgan.py:20-431): an auto-encoder "detector" in front of
-    the MMD, trained in alternation with the generator.  Runs module-by-module on the HIP operators
-    (Linear, upper_softmax, MMD) under autograd; see DESIGN.md for what is fused and what is not."""
+    the MMD, trained in alternation with the generator.  Runs on its own step engine (kl_trainer.KLStepEngine: explicit
+    forward/backward on the HIP kernels, no autograd, each step kind replayed from a captured HIP graph); DESIGN.md section 7."""
 
     def __init__(self, batch_size=500, temperature=0, epochs=2000, lr_G=0.007, lr_D=0.007, iternum_d=1, iternum_g=5,
                  momentum=0.99, seed=777, weight_decay=0.04, path_to_directory=None):
