@@ -89,6 +89,14 @@ int vgan_col_mean(const float* data, int ldd, int rows, int d, float* out, vgan_
 int vgan_gather_rows(const float* data, int ldd, const int32_t* rows, const uint64_t* row_cursor,
                      int row_batches, int row_stride, int row_offset, float* out, int ldo,
                      float* sq, int n, int d, vgan_stream_t stream);
+/* The X half of the (centred) MMD operand alone, for a batch whose mask does not exist yet: out[i] = data[rows[i]] - center
+ * (out may be NULL), sq[i] its squared norm (of the split values when norm_split != 0), Zh/Zl[i] (may be NULL) its bf16
+ * hi/lo images with row stride kp.  The data-parallel step runs it for the NEXT batch while the gradient all-reduce is in
+ * flight; the X-X tiles of the next Gram (sums only) then run behind the collective as well. */
+int vgan_gather_rows_split(const float* data, int ldd, const int32_t* rows, const uint64_t* row_cursor,
+                           int row_batches, int row_stride, int row_offset, const float* center, float* out,
+                           int ldo, float* sq, int norm_split, uint16_t* Zh, uint16_t* Zl, int kp, int n, int d,
+                           vgan_stream_t stream);
 /* dlogits = softmax-Jacobian( [S < 1/d] * (gU + penalty_grad) ), the autograd of Generator.py:19-21.
  * colkey (may be NULL): packed column arg-max keys from vgan_colmax; row r of column j gets
  * -pen_weight/d added when it holds column j's maximum (topk(U,1,0), Mmd_loss_constrained.py:50). */
@@ -140,6 +148,9 @@ int vgan_upper_softmax_forward(const float* logits, int ldl, float* S, float* U,
  * tile: edge of the square tiles, 64 (every kernel) or 128 (vgan_mmd_gram_bf3 only).
  * Returns the number of tiles (or -1 if cap is too small); out may be NULL to query the count. */
 int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int tile, int32_t* out, int cap);
+/* Re-applies the XCD-aware launch order (Morton curve, dealt to the 8 XCDs in contiguous chunks) to a table the caller
+ * filtered or re-assembled on the host, e.g. the X-X tiles split off for the launch that overlaps the gradient all-reduce. */
+int vgan_mmd_order_tiles(int32_t* tiles, int count, int tile);
 
 /* partial[tiles*4] (float): per tile {sum K, sum L, 0, 0}.  calibrate != 0: only sum L is
  * produced (first-call bandwidth, Mmd_loss_constrained.py:16-20) and bw/Wg are not touched. */
@@ -323,6 +334,22 @@ int vgan_mse(const float* a, int lda, const float* b, int ldb, int n, int d, flo
 int vgan_mse_grad(const float* target, int ldt, const float* pred, int ldp, int n, int d, float gscale,
                   double* part, float* g, int ldg, vgan_stream_t stream);
 int vgan_sum_f64(const double* in, int count, double scale, float* out, int accumulate, vgan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data-parallel exchange  (the reference has no collective): thin wrappers over RCCL for callers that do not
+ * use torch.distributed.  One process per GPU.  Rank 0 calls vgan_dp_unique_id and hands the 128 bytes to every rank by
+ * its own means; each rank then creates its communicator and, once per step, all-reduces (SUM, in place, float32) the
+ * generator gradient on the stream the step's kernels run on -- after vgan_linear_backward_params has produced M_4 (or the
+ * flat gradient), before the products that consume it.  To overlap it, issue it on a second stream and run
+ * vgan_gather_rows_split + the X-X tiles of the next batch meanwhile (what v-gan_amd/trainer.py does).
+ * RCCL is dlopen'ed at first use: without librccl.so these calls return VGAN_ERR_HIP and everything else still works.
+ * ------------------------------------------------------------------------------------------- */
+#define VGAN_DP_ID_BYTES 128
+typedef struct vgan_dp_comm vgan_dp_comm;
+int vgan_dp_unique_id(uint8_t* id /* [VGAN_DP_ID_BYTES] */);
+int vgan_dp_comm_create(vgan_dp_comm** comm, int nranks, const uint8_t* id, int rank);
+int vgan_dp_allreduce_sum(vgan_dp_comm* comm, float* buf, int64_t count, vgan_stream_t stream);
+int vgan_dp_comm_destroy(vgan_dp_comm* comm);
 
 /* ---------------------------------------------------------------------------------------------
  * Input pipeline / sampling post-processing on the device  

@@ -25,9 +25,13 @@ class CpuOps:
     def __init__(self):
         self.lib = _lib.load()  # host-side helpers of the .so (tile tables) work without a GPU
 
-    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64):
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64, split_xx=False):
         flat, cnt = _lib.build_tiles(n, grad_mode, rank, world, tile)
-        return torch.tensor(flat, dtype=torch.int32).view(cnt, 8)
+        table = torch.tensor(flat, dtype=torch.int32).view(cnt, 8)
+        if split_xx:
+            main, xx = _lib.split_tiles(table, tile)
+            return torch.cat([main, xx]), main.shape[0]
+        return table
 
     def colmax_chunks(self, n):
         return self.lib.vgan_colmax_chunks(n)
@@ -124,6 +128,23 @@ class CpuOps:
         out[:, :d].copy_(torch.as_tensor(X))
         if sq is not None:
             sq.copy_(torch.as_tensor((X.astype(np.float64) ** 2).sum(1)))
+
+    def gather_rows_split(self, data, rows, center, out, sq, norm_split=False, Zh=None, Zl=None, row_cursor=None, row_batches=1,
+                          row_stride=0, row_offset=0, n=None):
+        d = data.shape[1]
+        n = int(n if n is not None else (out.shape[0] if out is not None else sq.numel()))
+        X = _np(data)[self._rows(rows, row_cursor, row_batches, row_stride, row_offset, n)]
+        if center is not None:
+            X = X - _np(center)[:d]
+        if out is not None:
+            out[:, :d].copy_(torch.as_tensor(X))
+        hi, lo = self._split(X)
+        if Zh is not None:
+            Zh[:n, :d] = hi.view(torch.int16)
+            Zl[:n, :d] = lo.view(torch.int16)
+        if sq is not None:
+            Xn = (hi.float() + lo.float()).numpy() if norm_split else X
+            sq[:n].copy_(torch.as_tensor((Xn.astype(np.float64) ** 2).sum(1)))
 
     def upper_softmax_forward(self, logits, S, U):
         u, s = orc.upper_softmax_forward(_np(logits).astype(np.float32))

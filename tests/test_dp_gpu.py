@@ -83,3 +83,25 @@ def test_two_ranks_on_the_real_kernels(case, n, precision, steps, tmp_path):
     if case == "c1":
         g = load_golden("f3_traj_c1.npz")
         assert np.abs(r0["losses"] - g["losses"][:steps]).max() < 2e-5   # and of the reference's own run
+
+
+def test_rccl_wrappers_of_the_c_abi_single_rank():
+    """vgan_dp_*: the RCCL wrappers a non-torch caller of the C ABI uses for the step's one collective.  A one-GPU box can
+    only form a single-member communicator: id -> communicator -> in-place all-reduce(SUM) on the current stream (also
+    inside a side stream, as the overlapped schedule issues it) -> destroy."""
+    from vgan_amd.ops import HipOps
+    ops = HipOps()
+    uid = ops.dp_unique_id()
+    assert len(uid) == 128
+    comm = ops.dp_comm_create(1, uid, 0)
+    t = torch.arange(40000, dtype=torch.float32, device="cuda")
+    want = t.clone()
+    ops.dp_allreduce_sum(comm, t)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.dp_allreduce_sum(comm, t)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
+    ops.dp_comm_destroy(comm)

@@ -339,6 +339,16 @@ static void order_tiles_for_xcds(int32_t* tiles, int count, int T) {
     }
 }
 
+// XCD-aware order (see order_tiles_for_xcds) for a table the caller has filtered or concatenated itself
+extern "C" int vgan_mmd_order_tiles(int32_t* tiles, int count, int tile) {
+    if (tiles == nullptr || count < 0 || (tile != 64 && tile != 128)) {
+        set_error("vgan_mmd_order_tiles: bad argument");
+        return VGAN_ERR_ARG;
+    }
+    if (count > 1) order_tiles_for_xcds(tiles, count, tile);
+    return VGAN_OK;
+}
+
 extern "C" int vgan_abi_version(void) { return VGAN_ABI_VERSION; }
 extern "C" const char* vgan_last_error(void) { return g_err; }
 

@@ -390,6 +390,35 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     if (lane == 0 && sq) sq[i] = nx;
 }
 
+// The X half of the MMD operand alone, for a batch whose mask is not known yet: Zx[i] = data[rows[i]] - c with its norm and
+// (optionally) its split images.  The data-parallel step runs this for the NEXT batch while the gradient all-reduce is in
+// flight, so that the X-X tiles of the next Gram (which need nothing else) can run behind the collective too.
+__global__ __launch_bounds__(kBlock) void gather_center_split_kernel(const float* __restrict__ data, int ldd, RowSel rows,
+                                                                    const float* __restrict__ center, float* __restrict__ out, int ldo,
+                                                                    float* __restrict__ sq, int norm_split,
+                                                                    unsigned short* __restrict__ Zh, unsigned short* __restrict__ Zl,
+                                                                    int kp, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* x = data + rows(i) * ldd;
+    float nx = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        const float v = x[j] - (center ? center[j] : 0.f);
+        if (out) out[(long)i * ldo + j] = v;
+        unsigned short hi, lo;
+        split_bf16(v, hi, lo);
+        if (Zh) {
+            Zh[(long)i * kp + j] = hi;
+            Zl[(long)i * kp + j] = lo;
+        }
+        const float vn = norm_split ? bf16_val(hi) + bf16_val(lo) : v;
+        nx = fmaf(vn, vn, nx);
+    }
+    nx = wave_sum(nx);
+    if (lane == 0 && sq) sq[i] = nx;
+}
+
 __global__ void mask_from_softmax_kernel(const float* __restrict__ S, int lds, float* __restrict__ U, int ldu, int n, int d) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * d) return;
@@ -490,6 +519,18 @@ extern "C" int vgan_gather_rows(const float* data, int ldd, const int32_t* rows,
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream, data,
                        ldd, sel, out, ldo, sq, n, d);
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_gather_rows_split(const float* data, int ldd, const int32_t* rows, const uint64_t* row_cursor, int row_batches,
+                                      int row_stride, int row_offset, const float* center, float* out, int ldo, float* sq,
+                                      int norm_split, uint16_t* Zh, uint16_t* Zl, int kp, int n, int d, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(data && n > 0 && d > 0 && ldd >= d && row_batches >= 1 && row_stride >= 0 && row_offset >= 0);
+    VGAN_CHECK_ARG((out == nullptr || ldo >= d) && (out || sq || Zh) && (Zh == nullptr) == (Zl == nullptr) && (Zh == nullptr || kp >= d));
+    const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
+    hipLaunchKernelGGL(gather_center_split_kernel, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream,
+                       data, ldd, sel, center, out, ldo, sq, norm_split, Zh, Zl, kp, n, d);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p]),
     "vgan_col_mean": (_i, [_p, _i, _i, _i, _p, _p]),
     "vgan_gather_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
+    "vgan_gather_rows_split": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p]),
     "vgan_mask_backward": (_i, [_p, _i, _i, _i64, _p, _i, _p, _f, _i, _p, _i, _i, _i, _p]),
     "vgan_colmax_partial": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "vgan_mmd_finalize": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _f, _p, _p, _p, _f, _p, _p]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "vgan_mask_from_softmax": (_i, [_p, _i, _p, _i, _i, _i, _p]),
     "vgan_upper_softmax_forward": (_i, [_p, _i, _p, _p, _i, _i, _p]),
     "vgan_mmd_build_tiles": (_i, [_i, _i, _i, _i, _i, _p, _i]),
+    "vgan_mmd_order_tiles": (_i, [_p, _i, _i]),
     "vgan_mmd_gram": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _p, _p]),
     "vgan_mmd_gram_general": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _p, _p]),
     "vgan_mmd_gram_colmax": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
@@ -73,6 +75,10 @@ SIGNATURES = {
     "vgan_shuffle_epoch": (_i, [_p, _i64, _i64, _u64, _u64, _p]),
     "vgan_shuffle_index": (_i64, [_i64, _i64, _u64, _u64]),
     "vgan_mask_unique": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "vgan_dp_unique_id": (_i, [_p]),
+    "vgan_dp_comm_create": (_i, [_p, _i, _p, _i]),
+    "vgan_dp_allreduce_sum": (_i, [_p, _p, _i64, _p]),
+    "vgan_dp_comm_destroy": (_i, [_p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 
@@ -121,3 +127,21 @@ def build_tiles(n, grad_mode, rank=0, world=1, tile=64):
     if got != cnt:
         raise VganHipError("vgan_mmd_build_tiles: inconsistent tile count")
     return list(buf), cnt
+
+
+def split_tiles(table, tile=64):
+    """Splits a tile table (torch int32 [count, 8], host) into (tiles of the XY / YY blocks, tiles of the XX block), each
+    re-ordered for the XCDs.  The XX tiles only feed the reported loss (sums, no gradient weights): the data-parallel step
+    runs them in a launch of their own, behind the gradient all-reduce."""
+    import torch
+    lib = load()
+    parts = []
+    for keep in (table[:, 4] & 3 != 0, table[:, 4] & 3 == 0):
+        sub = table[keep].contiguous()
+        if sub.shape[0] > 1:
+            buf = (ctypes.c_int32 * sub.numel())(*sub.reshape(-1).tolist())
+            if lib.vgan_mmd_order_tiles(ctypes.cast(buf, ctypes.c_void_p), sub.shape[0], tile) != 0:
+                raise VganHipError("vgan_mmd_order_tiles: " + lib.vgan_last_error().decode())
+            sub = torch.tensor(list(buf), dtype=torch.int32).view(-1, 8)
+        parts.append(sub)
+    return parts

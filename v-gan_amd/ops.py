@@ -47,9 +47,15 @@ class HipOps:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ---- host helpers -----------------------------------------------------------------------
-    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64):
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64, split_xx=False):
+        """split_xx: the table is returned as [XY and YY tiles ... | XX tiles ...] (each part in XCD order) together with the
+        length of the first part, for callers that launch the sum-only XX tiles separately."""
         flat, cnt = _lib.build_tiles(n, grad_mode, rank, world, tile)
-        return torch.tensor(flat, dtype=torch.int32).view(cnt, 8).to(device or "cuda")
+        table = torch.tensor(flat, dtype=torch.int32).view(cnt, 8)
+        if split_xx:
+            main, xx = _lib.split_tiles(table, tile)
+            return torch.cat([main, xx]).to(device or "cuda"), main.shape[0]
+        return table.to(device or "cuda")
 
     def colmax_chunks(self, n):
         return self.lib.vgan_colmax_chunks(n)
@@ -130,6 +136,18 @@ class HipOps:
         _lib.check(self.lib.vgan_gather_rows(_ptr(data), data.stride(0), _ptr(rows), _ptr(row_cursor), int(row_batches),
                                              int(row_stride), int(row_offset), _ptr(out), out.stride(0), _ptr(sq), n, d,
                                              self._stream()), "vgan_gather_rows")
+
+    def gather_rows_split(self, data, rows, center, out, sq, norm_split=False, Zh=None, Zl=None, row_cursor=None, row_batches=1,
+                          row_stride=0, row_offset=0, n=None):
+        """X half of the centred MMD operand for the batch the cursor points at: out / sq / split images (each optional)."""
+        _mat(data, "data")
+        d = data.shape[1]
+        n = int(n if n is not None else (out.shape[0] if out is not None else sq.numel()))
+        _lib.check(self.lib.vgan_gather_rows_split(_ptr(data), data.stride(0), _ptr(rows), _ptr(row_cursor), int(row_batches),
+                                                   int(row_stride), int(row_offset), _ptr(center), _ptr(out),
+                                                   out.stride(0) if out is not None else 0, _ptr(sq), int(bool(norm_split)), _ptr(Zh),
+                                                   _ptr(Zl), Zh.stride(0) if Zh is not None else 0, n, d, self._stream()),
+                   "vgan_gather_rows_split")
 
     def upper_softmax_forward(self, logits, S, U):
         _mat(logits, "logits")
@@ -334,6 +352,26 @@ class HipOps:
         assert out.dtype == torch.float64 and out.numel() >= rows
         ldb = 0 if broadcast_b else B.stride(0)
         _lib.check(self.lib.vgan_rows_dot(_ptr(A), A.stride(0), _ptr(B), ldb, _ptr(out), rows, cols, self._stream()), "vgan_rows_dot")
+
+    # ---- data-parallel exchange through the C ABI (RCCL; the step engine itself uses torch.distributed) ------------
+    def dp_unique_id(self):
+        buf = (ctypes.c_uint8 * 128)()
+        _lib.check(self.lib.vgan_dp_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "vgan_dp_unique_id")
+        return bytes(buf)
+
+    def dp_comm_create(self, nranks, unique_id, rank):
+        comm = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self.lib.vgan_dp_comm_create(ctypes.byref(comm), int(nranks), ctypes.cast(buf, ctypes.c_void_p), int(rank)),
+                   "vgan_dp_comm_create")
+        return comm
+
+    def dp_allreduce_sum(self, comm, t):
+        _vec(t, "t")
+        _lib.check(self.lib.vgan_dp_allreduce_sum(comm, _ptr(t), t.numel(), self._stream()), "vgan_dp_allreduce_sum")
+
+    def dp_comm_destroy(self, comm):
+        _lib.check(self.lib.vgan_dp_comm_destroy(comm), "vgan_dp_comm_destroy")
 
     # ---- input pipeline / sampling post-processing on the device ------------------------------------
     def shuffle_epoch(self, perm, train_size, seed, epoch):

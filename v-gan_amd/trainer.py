@@ -86,7 +86,7 @@ class FlatParams:
 class NoKLStepEngine:
     def __init__(self, ops, generator, data, batch_size, batches_per_epoch, lr=0.007, weight_decay=0.04, penalty_weight=10.0,
                  seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None,
-                 generator_mode=None, force_exchange=False, mmd_precision=None, center_operand=True):
+                 generator_mode=None, force_exchange=False, mmd_precision=None, center_operand=True, overlap_exchange=None):
         self.ops = ops
         self.dev = data.device
         self.rank, self.world, self.group = rank, world, group
@@ -107,6 +107,7 @@ class NoKLStepEngine:
         self.use_graph = bool(use_graph) and data.is_cuda
         self.graph = None
         self.steps_done = 0
+        self._xx_primed = False  # overlap mode: have the X-X sums of the upcoming batch been computed?
         self.mode = generator_mode or os.environ.get("VGAN_GENERATOR", "collapsed")
         if self.mode not in ("collapsed", "layered"):
             raise ValueError(f"generator_mode must be 'collapsed' or 'layered', got {self.mode!r}")
@@ -223,10 +224,21 @@ class NoKLStepEngine:
         if self.bf3 and nl % 128 == 0 and want in ("auto", "128"):
             if want == "128" or len(ops.build_tiles(n, 1, rank, world, device=self.dev, tile=128)) >= 512:
                 self.gram_tile = 128
-        self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile)
+        # Comm/compute overlap of the data-parallel step: the gradient all-reduce runs on a side stream while the main stream
+        # does the only work of the NEXT step that needs no updated parameter -- the X half of its operand (gather, centre,
+        # split) and the X-X tiles of its Gram, which feed nothing but the reported loss.  The table is then laid out as
+        # [XY and YY tiles | XX tiles]: the step's Gram launch covers the first part, the overlapped launch the second, and
+        # the step tail folds both (one table, one partial buffer).
+        self.overlap = self.exchange if overlap_exchange is None else (bool(overlap_exchange) and self.exchange)
+        self._side = torch.cuda.Stream(device=self.dev) if (self.overlap and data.is_cuda) else None
+        if self.overlap:
+            self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
+        else:
+            self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile)
+            self.n_main = self.tiles.shape[0]
         # the first-call bandwidth needs sum(L) over ALL pairs: computed by every rank from the full table (no collective)
         # (the calibration launch is the fp32 kernel: 64-wide tiles)
-        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
+        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not self.overlap) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
         self.partial = torch.zeros(max(self.tiles.shape[0], self.tiles_cal.shape[0]), 4, **f32)
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
@@ -242,11 +254,52 @@ class NoKLStepEngine:
     def set_epoch_batches(self, idx):
         """idx: [batches_per_epoch, n] integer tensor of shuffled row indices (DataLoader order)."""
         self.perm.copy_(idx.to(dtype=torch.int32), non_blocking=True)
+        self._after_new_epoch_table()
+
+    def _after_new_epoch_table(self):
+        # overlap mode: the X-X sums of the batch the cursor points at were computed behind the previous step's all-reduce
+        # from the OLD table; redo them for the new one (the first step of an epoch pays for them, the others do not)
+        if self.overlap and self.has_bw:
+            self._prefetch_xx()
+
+    def _prefetch_xx(self):
+        """X half of the operand of the batch the device-side cursor points at, and its X-X tiles (sums only)."""
+        ops, n, nl, lo = self.ops, self.n, self.nl, self.lo
+        rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
+        ntx = self.tiles.shape[0] - self.n_main
+        self._xx_primed = True
+        if ntx == 0:
+            return
+        tx, px = self.tiles[self.n_main:], self.partial[self.n_main:self.n_main + ntx]
+        if self.bf3:
+            ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], True, self.Zh[:n], self.Zl[:n], **rowsel)
+            ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, tx, None, None, 0, px, tile=self.gram_tile)
+        else:
+            ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], False, **rowsel)
+            ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, tx, False, None, 0, px)
+
+    def _all_reduce_overlapped(self, dist, tensor):
+        """all-reduce(SUM) of the generator gradient on the side stream, with the next step's parameter-independent work
+        (`_prefetch_xx`) on the main stream; joined before the first launch that reads the reduced gradient."""
+        if not self.overlap:
+            dist.all_reduce(tensor, group=self.group)
+            return
+        if self._side is None:  # CPU provider (tests): same order of operations, no streams
+            dist.all_reduce(tensor, group=self.group)
+            self._prefetch_xx()
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            dist.all_reduce(tensor, group=self.group)
+        self._prefetch_xx()
+        main.wait_stream(self._side)
 
     def shuffle_epoch(self, epoch):
         """This epoch's shuffled drop_last batches from the device-side counter-based permutation (vgan_shuffle_epoch), keyed
         by (seed, epoch): identical on every rank, no host draw and no H2D copy."""
         self.ops.shuffle_epoch(self.perm, self.data.shape[0], self.seed, int(epoch))
+        self._after_new_epoch_table()
 
     def set_bandwidth(self, value):
         self.bw.fill_(float(value))
@@ -309,7 +362,7 @@ class NoKLStepEngine:
             if dist:
                 if self.splits > 1:
                     ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
-                dist.all_reduce(self.fp.grad, group=self.group)
+                self._all_reduce_overlapped(dist, self.fp.grad)
                 ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, **adadelta)
             elif self.splits > 1:  # no exchange: Adadelta sums the slabs itself
                 ops.adadelta_step(self.fp.flat, self.gslab[0], self.fp.sq, self.fp.acc, nslabs=self.splits, slab_stride=self.fp.total,
@@ -323,7 +376,7 @@ class NoKLStepEngine:
         # slab-summing staging loads in the consumers, were both measured slower)
         ops.linear_backward_params(self.dlogits_pad, self.z_own, self.M[4][:self.dp], None)  # pad columns are zero: rows d.. of M_4 too
         if dist:
-            dist.all_reduce(self.M[4], group=self.group)
+            self._all_reduce_overlapped(dist, self.M[4])
         # M_{k-1} = Wt_k^T M_k, i.e. M_3 = Wt_4^T M_4, M_2 = B_3^T M_4, M_1 = B_2^T M_4 (At_0 = I: Gt_1 IS M_1), and
         # [dW_k | db_k] = Gt_k = M_k . At_{k-1}^T: two dependency levels
         M, Gt, At = self.M, self.Gt, self.At
@@ -372,10 +425,10 @@ class NoKLStepEngine:
         if bf3 and not self.fused_prepare:
             ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
         if bf3:
-            ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles, self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
+            ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles[:self.n_main], self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
                              self.colpart, True, tile=self.gram_tile)
         else:
-            ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles, self.Wg, n + lo, self.partial, self.S, 0,
+            ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles[:self.n_main], self.Wg, n + lo, self.partial, self.S, 0,
                                 self.colpart, True)
         # the step tail (block sums -> stats, column keys, loss bookkeeping) rides in the backward launch as one extra
         # workgroup: its outputs are first needed by the mask backward, so it leaves the critical path.  With several
@@ -404,6 +457,8 @@ class NoKLStepEngine:
         if not self.has_bw:
             self._forward()
             self._calibrate()
+            if self.overlap:  # no step ran before this one: its X-X sums are computed here, with the fresh bandwidth
+                self._prefetch_xx()
             self._loss_backward_update()
         elif self.use_graph and self.steps_done > 0:
             if self.graph is None:
@@ -415,6 +470,8 @@ class NoKLStepEngine:
         else:
             # eager: graphs off, or the very first step of an engine whose bandwidth was handed over (a second fit in one
             # process: the shared-RBF quirk) -- its first-ever launches and the one-off noise draw stay outside the capture
+            if self.overlap and not self._xx_primed:
+                self._prefetch_xx()
             self._step_body()
         self.steps_done += 1
 
