@@ -267,6 +267,40 @@ typedef struct vgan_gemm_problem {
     int32_t kind, m, n, k, lda, ldb, ldc, pad;
 } vgan_gemm_problem;
 int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_t stream);
+/* The same launch with work riding in it (each part optional; a dependent launch costs ~5 us whatever its size, so the
+ * tail of the step shares launches):
+ *   copy      dst[i] = src[i], i < copy_count (a snapshot a later launch of the step reads while its source is updated);
+ *   adadelta  != 0: problem i's output C_i is the packed gradient [dW | db] of layer[i] (rows < out, columns <= in, column
+ *             `in` = bias) and the torch.optim.Adadelta update (src/vgan.py:567-568, :619; rule of vgan_adadelta_step) runs in
+ *             the product's epilogue: the flat parameter p[off_w + row*in + col] / p[off_b + row], its state, and the packed
+ *             weight w_packed[row*ldp + col] are updated in place (C_i is still written).  None of the launch's operands
+ *             may alias an updated w_packed.  g_extra != NULL: one more layer, layer[count], whose packed gradient already
+ *             sits in memory (row stride ld_extra) is updated element-wise by surplus workgroups;
+ *   noise     next_noise != NULL: the next step's noise draw, as in vgan_adadelta_step_packed. */
+typedef struct vgan_adadelta_layer {
+    float* w_packed;
+    int64_t off_w, off_b;
+    int32_t ldp, out, in, pad;
+} vgan_adadelta_layer;
+typedef struct vgan_grouped_extras {
+    const float* copy_src;
+    float* copy_dst;
+    int64_t copy_count;
+    int32_t adadelta, pad;
+    float* p;
+    float* sq_avg;
+    float* acc_delta;
+    float lr, rho, eps, weight_decay, grad_scale;
+    int32_t ld_extra;
+    vgan_adadelta_layer layer[VGAN_GEMM_MAX_GROUP + 1];
+    const float* g_extra;
+    float* next_noise;
+    int32_t noise_rows, noise_cols, noise_ld, noise_ones_col;
+    uint64_t seed;
+    const uint64_t* step_counter;
+} vgan_grouped_extras;
+int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count, const vgan_grouped_extras* extras,
+                         vgan_stream_t stream);
 
 /* vgan_mask_project_forward fused with vgan_mmd_bf3_prepare for the training step: from logits [n, d] and the
  * batch rows it writes S [n, d], Z = [X ; U*X] ([2n, ldz] fp32), sq [2n] and the split images Zh, Zl [2n, kp],

@@ -354,13 +354,32 @@ class CpuOps:
     def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
         return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 
-    def gemm_grouped(self, problems):
+    def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None):
         outs = []
         for kind, A, B, C in problems:  # all reads before any write: the products are independent by contract
             a, b = _np(A).astype(np.float64), _np(B).astype(np.float64)
             outs.append(a @ b if kind == "NN" else a @ b.T if kind == "NT" else a.T @ b)
+        if noise is not None:  # reads the step counter as the launch finds it
+            self.noise_normal(noise["next_noise"], noise["seed"], noise["step_counter"], 0, cols=noise["noise_cols"],
+                              ones_col=noise["noise_ones_col"])
+        if copy is not None:
+            copy[1].copy_(copy[0])
         for (_, _, _, C), r in zip(problems, outs):
             C.copy_(torch.as_tensor(r))
+        if adadelta is not None:
+            a = adadelta
+            grads = [C for _, _, _, C in problems] + ([a["extra_grad"]] if a.get("extra_grad") is not None else [])
+            for (w, off_w, off_b, out, inp), G in zip(a["layers"], grads):
+                for off, cnt, g in ((off_w, out * inp, G[:out, :inp].reshape(-1)), (off_b, out, G[:out, inp].reshape(-1))):
+                    sl = slice(off, off + cnt)
+                    pn, sn, an = orc.adadelta_step(_np(a["p"])[sl].astype(np.float64), _np(g).astype(np.float64) * a.get("grad_scale", 1.0),
+                                                   _np(a["sq"])[sl].astype(np.float64), _np(a["acc"])[sl].astype(np.float64), a["lr"],
+                                                   a.get("weight_decay", 0.0), a.get("rho", 0.9), a.get("eps", 1e-6))
+                    a["p"][sl].copy_(torch.as_tensor(pn))
+                    a["sq"][sl].copy_(torch.as_tensor(sn))
+                    a["acc"][sl].copy_(torch.as_tensor(an))
+                w[:out, :inp].copy_(a["p"][off_w:off_w + out * inp].view(out, inp))
+                w[:out, inp].copy_(a["p"][off_b:off_b + out])
 
     def mse_grad(self, target, pred, gscale, part, g):
         n, d = pred.shape

@@ -36,13 +36,15 @@ for graph in (() if only else (False, True)):
 import time
 if world == 1:
     for G in ((int(only),) if only else (1, 2, 4, 8)):
-        eng, data, params = bench.build_engine(0, G, True, force_exchange=True)
-        bench.run_steps(eng, 64, 0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        bench.run_steps(eng, 800, 64)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 800
-        print(f"emulated shard 1/{G}: {dt * 1e6:.1f} us per step per rank ({1.0 / dt:.0f} steps/s if collectives were free)")
+        for schedule in (False, "serial", True):  # plain | overlapped schedule on one stream | overlapped on a side stream
+            eng, data, params = bench.build_engine(0, G, True, force_exchange=True, overlap_exchange=schedule)
+            bench.run_steps(eng, 64, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bench.run_steps(eng, 800, 64)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 800
+            print(f"emulated shard 1/{G}, exchange schedule {schedule!s:6s}: {dt * 1e6:.1f} us per step per rank "
+                  f"({1.0 / dt:.0f} steps/s if collectives were free)", flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -5,6 +5,7 @@
 // on each other share a launch.  Per problem the library picks the tile engine: 32x32 tiles with K split over the waves
 // (GemmTileKS) when the 64x64 grid would be a handful of long-K tiles, 64x64x32 tiles otherwise.
 #include "gemm_core.hpp"
+#include "optim_common.hpp"
 
 namespace vgan {
 
@@ -17,8 +18,58 @@ struct GroupedArgs {
     int count;
 };
 
-template <int LA, int LB, int VEC>
-__device__ __forceinline__ void tile64(const vgan_gemm_problem& q, int t, float* lds) {
+// What may ride in a grouped launch besides its products (vgan_gemm_grouped_ex): a plain copy, the Adadelta update as
+// the products' epilogue (+ one element-wise layer whose gradient already sits in memory), and the next step's noise draw.
+struct GroupedExtras {
+    const float* copy_src;
+    float* copy_dst;
+    long copy_count;
+    int copy_blocks, extra_blocks, noise_blocks, adadelta;
+    float *p, *sq, *acc;
+    float lr, rho, eps, wd, gs;
+    vgan_adadelta_layer layer[VGAN_GEMM_MAX_GROUP + 1];
+    const float* g_extra;
+    int ld_extra;
+    float* z;
+    int zrows, zcols, zld, zones;
+    unsigned long long seed;
+    const unsigned long long* step_counter;
+};
+
+// the optimiser step of one element of a packed gradient image [dW | db]: (row, col) -> flat parameter index
+__device__ __forceinline__ void adadelta_packed_element(const GroupedExtras& x, const vgan_adadelta_layer& L, int row, int col, float g) {
+    if (row >= L.out || col > L.in) return;
+    const long idx = col < L.in ? L.off_w + (long)row * L.in + col : L.off_b + row;
+    float pv = x.p[idx], v = x.sq[idx], a = x.acc[idx];
+    adadelta_one(pv, g, v, a, x.lr, x.rho, x.eps, x.wd, x.gs);
+    x.p[idx] = pv;
+    x.sq[idx] = v;
+    x.acc[idx] = a;
+    L.w_packed[(long)row * L.ldp + col] = pv;
+}
+
+// workgroups past the product tiles: copy | element-wise layer | noise (block-uniform dispatch)
+__device__ __forceinline__ void grouped_extra_jobs(const GroupedExtras& x, int b, int layer_index) {
+    if (b < x.copy_blocks) {
+        for (long i = (long)b * blockDim.x + threadIdx.x; i < x.copy_count; i += (long)x.copy_blocks * blockDim.x) x.copy_dst[i] = x.copy_src[i];
+        return;
+    }
+    b -= x.copy_blocks;
+    if (b < x.extra_blocks) {
+        const vgan_adadelta_layer& L = x.layer[layer_index];
+        const long total = (long)L.out * (L.in + 1);
+        for (long i = (long)b * blockDim.x + threadIdx.x; i < total; i += (long)x.extra_blocks * blockDim.x) {
+            const int row = (int)(i / (L.in + 1)), col = (int)(i % (L.in + 1));
+            adadelta_packed_element(x, L, row, col, x.g_extra[(long)row * x.ld_extra + col]);
+        }
+        return;
+    }
+    b -= x.extra_blocks;
+    if (b < x.noise_blocks) noise_normal_body(x.z, x.zrows, x.zcols, x.zld, x.zones, x.seed, x.step_counter, 0ull, b, x.noise_blocks);
+}
+
+template <int LA, int LB, int VEC, bool EPI>
+__device__ __forceinline__ void tile64(const vgan_gemm_problem& q, int t, float* lds, const GroupedExtras& x, int qi) {
     using G = GemmTile<QBM, QBM, QBK, LA, LB, VEC>;
     const int gx = (q.n + QBM - 1) / QBM;
     const int m0 = (t / gx) * QBM, n0 = (t % gx) * QBM;
@@ -29,12 +80,15 @@ __device__ __forceinline__ void tile64(const vgan_gemm_problem& q, int t, float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + G::sub_row(0, r);
-        if (row < q.m && col < q.n) q.c[(long)row * q.ldc + col] = acc[0][0][r];
+        if (row < q.m && col < q.n) {
+            q.c[(long)row * q.ldc + col] = acc[0][0][r];
+            if constexpr (EPI) adadelta_packed_element(x, x.layer[qi], row, col, acc[0][0][r]);
+        }
     }
 }
 
-template <int LA, int LB, int VEC, int NW = 4>
-__device__ __forceinline__ void tile_ks(const vgan_gemm_problem& q, int t, float* lds) {
+template <int LA, int LB, int VEC, int NW = 4, bool EPI = false>
+__device__ __forceinline__ void tile_ks(const vgan_gemm_problem& q, int t, float* lds, const GroupedExtras& x, int qi) {
     using G = GemmTileKS<QKS, LA, LB, VEC, NW>;
     const int gx = (q.n + 31) / 32;
     const int m0 = (t / gx) * 32, n0 = (t % gx) * 32;
@@ -44,18 +98,25 @@ __device__ __forceinline__ void tile_ks(const vgan_gemm_problem& q, int t, float
 #pragma unroll
     for (int rr = 0; rr < G::NR; ++rr) {
         const int row = m0 + G::row_of(rr);
-        if (row < q.m && col < q.n) q.c[(long)row * q.ldc + col] = o[rr];
+        if (row < q.m && col < q.n) {
+            q.c[(long)row * q.ldc + col] = o[rr];
+            if constexpr (EPI) adadelta_packed_element(x, x.layer[qi], row, col, o[rr]);
+        }
     }
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int VEC>
-__global__ __launch_bounds__(kBlock, 2) void gemm_grouped_kernel(GroupedArgs g) {
+template <int VEC, bool EPI>
+__global__ __launch_bounds__(kBlock, 2) void gemm_grouped_kernel(GroupedArgs g, GroupedExtras x) {
     constexpr int kLds = cmax(cmax(GemmTile<QBM, QBM, QBK, KC, MC, VEC>::kLdsFloats, GemmTile<QBM, QBM, QBK, MC, MC, VEC>::kLdsFloats),
                               cmax(cmax(GemmTileKS<QKS, KC, MC, VEC>::kLdsFloats, GemmTileKS<QKS, MC, MC, VEC>::kLdsFloats),
                                    cmax(GemmTile<QBM, QBM, QBK, KC, KC, VEC>::kLdsFloats, GemmTileKS<QKS, KC, KC, VEC>::kLdsFloats)));
     __shared__ __attribute__((aligned(16))) float lds[kLds];
+    if ((int)blockIdx.x >= g.tile_start[VGAN_GEMM_MAX_GROUP]) {  // block-uniform: the jobs riding behind the product tiles
+        grouped_extra_jobs(x, blockIdx.x - g.tile_start[VGAN_GEMM_MAX_GROUP], g.count);
+        return;
+    }
     int qi = 0;  // block-uniform
 #pragma unroll
     for (int i = 1; i < VGAN_GEMM_MAX_GROUP; ++i)
@@ -64,38 +125,49 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_grouped_kernel(GroupedArgs g) 
     const int t = blockIdx.x - g.tile_start[qi];
     // operand images: KC = contraction index contiguous ([mn][K]), MC = output index contiguous ([K][mn])
     if (q.kind == VGAN_GEMM_NN) {         // C = A[m,k] . B[k,n]
-        if (g.ks[qi]) tile_ks<KC, MC, VEC>(q, t, lds); else tile64<KC, MC, VEC>(q, t, lds);
+        if (g.ks[qi]) tile_ks<KC, MC, VEC, 4, EPI>(q, t, lds, x, qi); else tile64<KC, MC, VEC, EPI>(q, t, lds, x, qi);
     } else if (q.kind == VGAN_GEMM_NT) {  // C = A[m,k] . B[n,k]^T
-        if (g.ks[qi]) tile_ks<KC, KC, VEC>(q, t, lds); else tile64<KC, KC, VEC>(q, t, lds);
+        if (g.ks[qi]) tile_ks<KC, KC, VEC, 4, EPI>(q, t, lds, x, qi); else tile64<KC, KC, VEC, EPI>(q, t, lds, x, qi);
     } else {                              // C = A[k,m]^T . B[k,n]
-        if (g.ks[qi]) tile_ks<MC, MC, VEC>(q, t, lds); else tile64<MC, MC, VEC>(q, t, lds);
+        if (g.ks[qi]) tile_ks<MC, MC, VEC, 4, EPI>(q, t, lds, x, qi); else tile64<MC, MC, VEC, EPI>(q, t, lds, x, qi);
     }
 }
 
 // Every problem on 32x32 tiles with 16 waves splitting K (1024-thread workgroups): launches whose products all have a long
 // contraction, where the per-wave MFMA chain is the critical path.
-__global__ __launch_bounds__(1024, 1) void gemm_grouped_ks16_kernel(GroupedArgs g) {
+__global__ __launch_bounds__(1024, 1) void gemm_grouped_ks16_kernel(GroupedArgs g, GroupedExtras x) {
     constexpr int kLds = cmax(cmax(GemmTileKS<QKS, KC, MC, 4, 16>::kLdsFloats, GemmTileKS<QKS, MC, MC, 4, 16>::kLdsFloats),
                               GemmTileKS<QKS, KC, KC, 4, 16>::kLdsFloats);
     __shared__ __attribute__((aligned(16))) float lds[kLds];
+    if ((int)blockIdx.x >= g.tile_start[VGAN_GEMM_MAX_GROUP]) {  // (this variant carries the copy job only)
+        grouped_extra_jobs(x, blockIdx.x - g.tile_start[VGAN_GEMM_MAX_GROUP], g.count);
+        return;
+    }
     int qi = 0;
 #pragma unroll
     for (int i = 1; i < VGAN_GEMM_MAX_GROUP; ++i)
         if (i < g.count && (int)blockIdx.x >= g.tile_start[i]) qi = i;
     const vgan_gemm_problem& q = g.p[qi];
     const int t = blockIdx.x - g.tile_start[qi];
-    if (q.kind == VGAN_GEMM_NN) tile_ks<KC, MC, 4, 16>(q, t, lds);
-    else if (q.kind == VGAN_GEMM_NT) tile_ks<KC, KC, 4, 16>(q, t, lds);
-    else tile_ks<MC, MC, 4, 16>(q, t, lds);
+    if (q.kind == VGAN_GEMM_NN) tile_ks<KC, MC, 4, 16>(q, t, lds, x, qi);
+    else if (q.kind == VGAN_GEMM_NT) tile_ks<KC, KC, 4, 16>(q, t, lds, x, qi);
+    else tile_ks<MC, MC, 4, 16>(q, t, lds, x, qi);
 }
 
 }  // namespace vgan
 
 using namespace vgan;
 
-extern "C" int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_t stream) {
+static inline int extra_grid(long work_items) {
+    long g = (work_items + kBlock - 1) / kBlock;
+    return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+
+extern "C" int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count, const vgan_grouped_extras* extras,
+                                    vgan_stream_t stream) {
     VGAN_CHECK_ARG(problems && count >= 1 && count <= VGAN_GEMM_MAX_GROUP);
     GroupedArgs g{};
+    GroupedExtras x{};
     g.count = count;
     bool vec = true;
     int tiles = 0;
@@ -116,13 +188,53 @@ extern "C" int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, v
         tiles += g.ks[i] ? ((q.m + 31) / 32) * ((q.n + 31) / 32) : (int)t64;
     }
     for (int i = count; i <= VGAN_GEMM_MAX_GROUP; ++i) g.tile_start[i] = tiles;
-    // all products long-K and few tiles: one 1024-thread launch with every problem on 32x32 tiles
+    bool epi = false;
+    if (extras != nullptr) {
+        const vgan_grouped_extras& e = *extras;
+        if (e.copy_src != nullptr) {
+            VGAN_CHECK_ARG(e.copy_dst && e.copy_count > 0);
+            x.copy_src = e.copy_src;
+            x.copy_dst = e.copy_dst;
+            x.copy_count = (long)e.copy_count;
+            x.copy_blocks = extra_grid(e.copy_count);
+        }
+        if (e.adadelta) {
+            VGAN_CHECK_ARG(e.p && e.sq_avg && e.acc_delta);
+            epi = true;
+            x.adadelta = 1;
+            x.p = e.p; x.sq = e.sq_avg; x.acc = e.acc_delta;
+            x.lr = e.lr; x.rho = e.rho; x.eps = e.eps; x.wd = e.weight_decay; x.gs = e.grad_scale;
+            const int nl = count + (e.g_extra != nullptr ? 1 : 0);
+            for (int i = 0; i < nl; ++i) {
+                const vgan_adadelta_layer& L = e.layer[i];
+                VGAN_CHECK_ARG(L.w_packed && L.out > 0 && L.in > 0 && L.ldp >= L.in + 1 && L.off_w >= 0 && L.off_b >= 0);
+                if (i < count) VGAN_CHECK_ARG(problems[i].m >= L.out && problems[i].n >= L.in + 1);
+                x.layer[i] = L;
+            }
+            if (e.g_extra != nullptr) {
+                VGAN_CHECK_ARG(e.ld_extra >= e.layer[count].in + 1);
+                x.g_extra = e.g_extra;
+                x.ld_extra = e.ld_extra;
+                x.extra_blocks = extra_grid((long)e.layer[count].out * (e.layer[count].in + 1));
+            }
+        }
+        if (e.next_noise != nullptr) {
+            VGAN_CHECK_ARG(e.noise_rows > 0 && e.noise_cols > 0 && e.noise_ld >= e.noise_cols && e.noise_ones_col < e.noise_ld);
+            x.z = e.next_noise;
+            x.zrows = e.noise_rows; x.zcols = e.noise_cols; x.zld = e.noise_ld; x.zones = e.noise_ones_col;
+            x.seed = (unsigned long long)e.seed;
+            x.step_counter = reinterpret_cast<const unsigned long long*>(e.step_counter);
+            x.noise_blocks = extra_grid(((long)e.noise_rows * e.noise_cols + 3) / 4);
+        }
+    }
+    const int surplus = x.copy_blocks + x.extra_blocks + x.noise_blocks;
+    // all products long-K and few tiles: one 1024-thread launch with every problem on 32x32 tiles (no optimiser epilogue there)
     int kmin = problems[0].k, t32 = 0;
     for (int i = 0; i < count; ++i) {
         kmin = problems[i].k < kmin ? problems[i].k : kmin;
         t32 += ((problems[i].m + 31) / 32) * ((problems[i].n + 31) / 32);
     }
-    if (vec && kmin >= 96 && t32 <= 256) {
+    if (vec && kmin >= 96 && t32 <= 256 && !epi && x.noise_blocks == 0) {
         int acc = 0;
         for (int i = 0; i < count; ++i) {
             g.ks[i] = 1;
@@ -130,14 +242,20 @@ extern "C" int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, v
             acc += ((problems[i].m + 31) / 32) * ((problems[i].n + 31) / 32);
         }
         for (int i = count; i <= VGAN_GEMM_MAX_GROUP; ++i) g.tile_start[i] = acc;
-        hipLaunchKernelGGL(gemm_grouped_ks16_kernel, dim3(acc), dim3(1024), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(gemm_grouped_ks16_kernel, dim3(acc + surplus), dim3(1024), 0, (hipStream_t)stream, g, x);
         VGAN_CHECK_LAUNCH();
         return VGAN_OK;
     }
-    if (vec)
-        hipLaunchKernelGGL(gemm_grouped_kernel<4>, dim3(tiles), dim3(kBlock), 0, (hipStream_t)stream, g);
-    else
-        hipLaunchKernelGGL(gemm_grouped_kernel<1>, dim3(tiles), dim3(kBlock), 0, (hipStream_t)stream, g);
+    const dim3 grid(tiles + surplus), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec && epi) hipLaunchKernelGGL((gemm_grouped_kernel<4, true>), grid, block, 0, st, g, x);
+    else if (vec) hipLaunchKernelGGL((gemm_grouped_kernel<4, false>), grid, block, 0, st, g, x);
+    else if (epi) hipLaunchKernelGGL((gemm_grouped_kernel<1, true>), grid, block, 0, st, g, x);
+    else hipLaunchKernelGGL((gemm_grouped_kernel<1, false>), grid, block, 0, st, g, x);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
+}
+
+extern "C" int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_t stream) {
+    return vgan_gemm_grouped_ex(problems, count, nullptr, stream);
 }

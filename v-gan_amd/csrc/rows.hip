@@ -419,6 +419,43 @@ __global__ __launch_bounds__(kBlock) void gather_center_split_kernel(const float
     if (lane == 0 && sq) sq[i] = nx;
 }
 
+// 16 bytes per lane (d % 4 == 0, aligned bases and leading dimensions): the form the step engine's shapes take
+__global__ __launch_bounds__(kBlock) void gather_center_split_vec_kernel(const float* __restrict__ data, int ldd, RowSel rows,
+                                                                        const float* __restrict__ center, float* __restrict__ out, int ldo,
+                                                                        float* __restrict__ sq, int norm_split,
+                                                                        unsigned short* __restrict__ Zh, unsigned short* __restrict__ Zl,
+                                                                        int kp, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float4* x4 = reinterpret_cast<const float4*>(data + rows(i) * ldd);
+    const int nq = d >> 2;
+    float nx = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+        float4 v = x4[q];
+        if (center) {
+            const float4 c = reinterpret_cast<const float4*>(center)[q];
+            v.x -= c.x; v.y -= c.y; v.z -= c.z; v.w -= c.w;
+        }
+        if (out) reinterpret_cast<float4*>(out + (long)i * ldo)[q] = v;
+        const float vs[4] = {v.x, v.y, v.z, v.w};
+        unsigned short h[4], l[4];
+        float vn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            split_bf16(vs[e], h[e], l[e]);
+            vn[e] = norm_split ? bf16_val(h[e]) + bf16_val(l[e]) : vs[e];
+        }
+        if (Zh) {
+            *reinterpret_cast<uint2*>(Zh + (long)i * kp + 4 * q) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+            *reinterpret_cast<uint2*>(Zl + (long)i * kp + 4 * q) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+        }
+        nx += (vn[0] * vn[0] + vn[1] * vn[1]) + (vn[2] * vn[2] + vn[3] * vn[3]);
+    }
+    nx = wave_sum(nx);
+    if (lane == 0 && sq) sq[i] = nx;
+}
+
 __global__ void mask_from_softmax_kernel(const float* __restrict__ S, int lds, float* __restrict__ U, int ldu, int n, int d) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * d) return;
@@ -529,8 +566,15 @@ extern "C" int vgan_gather_rows_split(const float* data, int ldd, const int32_t*
     VGAN_CHECK_ARG(data && n > 0 && d > 0 && ldd >= d && row_batches >= 1 && row_stride >= 0 && row_offset >= 0);
     VGAN_CHECK_ARG((out == nullptr || ldo >= d) && (out || sq || Zh) && (Zh == nullptr) == (Zl == nullptr) && (Zh == nullptr || kp >= d));
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
-    hipLaunchKernelGGL(gather_center_split_kernel, dim3((n + kRowsPerBlock - 1) / kRowsPerBlock), dim3(kBlock), 0, (hipStream_t)stream,
-                       data, ldd, sel, center, out, ldo, sq, norm_split, Zh, Zl, kp, n, d);
+    const bool vec = (d % 4 == 0) && (ldd % 4 == 0) && aligned16(data) && (center == nullptr || aligned16(center)) &&
+                     (out == nullptr || (ldo % 4 == 0 && aligned16(out))) && (Zh == nullptr || (kp % 4 == 0 && aligned16(Zh) && aligned16(Zl)));
+    const dim3 grid((n + kRowsPerBlock - 1) / kRowsPerBlock), block(kBlock);
+    if (vec)
+        hipLaunchKernelGGL(gather_center_split_vec_kernel, grid, block, 0, (hipStream_t)stream, data, ldd, sel, center, out, ldo, sq, norm_split,
+                           Zh, Zl, kp, n, d);
+    else
+        hipLaunchKernelGGL(gather_center_split_kernel, grid, block, 0, (hipStream_t)stream, data, ldd, sel, center, out, ldo, sq, norm_split,
+                           Zh, Zl, kp, n, d);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -25,6 +25,21 @@ class GemmProblem(ctypes.Structure):
                 ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
+class AdadeltaLayer(ctypes.Structure):
+    """struct vgan_adadelta_layer (include/vgan_hip.h)."""
+    _fields_ = [("w_packed", _p), ("off_w", _i64), ("off_b", _i64), ("ldp", ctypes.c_int32), ("out", ctypes.c_int32),
+                ("inp", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+class GroupedExtras(ctypes.Structure):
+    """struct vgan_grouped_extras (include/vgan_hip.h): jobs riding in a grouped-GEMM launch."""
+    _fields_ = [("copy_src", _p), ("copy_dst", _p), ("copy_count", _i64), ("adadelta", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("p", _p), ("sq_avg", _p), ("acc_delta", _p), ("lr", _f), ("rho", _f), ("eps", _f), ("weight_decay", _f),
+                ("grad_scale", _f), ("ld_extra", ctypes.c_int32), ("layer", AdadeltaLayer * 5), ("g_extra", _p), ("next_noise", _p),
+                ("noise_rows", ctypes.c_int32), ("noise_cols", ctypes.c_int32), ("noise_ld", ctypes.c_int32),
+                ("noise_ones_col", ctypes.c_int32), ("seed", _u64), ("step_counter", _p)]
+
+
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 GEMM_MAX_GROUP = 4
 
@@ -66,6 +81,7 @@ SIGNATURES = {
     "vgan_homogeneous_pack": (_i, [_p, _i, _i, _i, _p]),
     "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _u64, _p, _p]),
     "vgan_gemm_grouped": (_i, [_p, _i, _p]),
+    "vgan_gemm_grouped_ex": (_i, [_p, _i, _p, _p]),
     "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p]),
     "vgan_mse_grad": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
     "vgan_sum_f64": (_i, [_p, _i, ctypes.c_double, _p, _i, _p]),

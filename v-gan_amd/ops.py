@@ -305,9 +305,14 @@ class HipOps:
         """Tile edge (64 / 128) mmd_backward_bf3 runs for this shape (host-side query of the library's rule)."""
         return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 
-    def gemm_grouped(self, problems):
+    def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None):
         """problems: up to 4 tuples (kind, A, B, C) with kind in "NN" (C = A.B), "NT" (C = A.B^T), "TN" (C = A^T.B); 2-D float32
-        tensors with unit inner stride.  One launch; the products must not depend on each other."""
+        tensors with unit inner stride.  One launch; the products must not depend on each other.  Jobs that may ride in the
+        launch (vgan_gemm_grouped_ex):
+          copy = (src, dst)             contiguous float32 tensors of equal size, dst <- src;
+          adadelta = dict(p, sq, acc, lr, rho, eps, weight_decay, grad_scale, layers=[(w_packed, off_w, off_b, out, in) per
+                     problem (+ one more with extra_grad)], extra_grad=None): the optimiser update in the products' epilogue;
+          noise = dict(next_noise, noise_cols, noise_ones_col, seed, step_counter): the next step's noise draw."""
         assert 1 <= len(problems) <= _lib.GEMM_MAX_GROUP
         arr = (_lib.GemmProblem * len(problems))()
         for q, (kind, A, B, C) in zip(arr, problems):
@@ -323,7 +328,36 @@ class HipOps:
             assert k == k2 and tuple(C.shape) == (m, n), (kind, tuple(A.shape), tuple(B.shape), tuple(C.shape))
             q.a, q.b, q.c, q.kind, q.m, q.n, q.k = A.data_ptr(), B.data_ptr(), C.data_ptr(), code, m, n, k
             q.lda, q.ldb, q.ldc = A.stride(0), B.stride(0), C.stride(0)
-        _lib.check(self.lib.vgan_gemm_grouped(arr, len(problems), self._stream()), "vgan_gemm_grouped")
+        if copy is None and adadelta is None and noise is None:
+            _lib.check(self.lib.vgan_gemm_grouped(arr, len(problems), self._stream()), "vgan_gemm_grouped")
+            return
+        x = _lib.GroupedExtras()
+        if copy is not None:
+            src, dst = copy
+            _vec(src, "copy src"), _vec(dst, "copy dst")
+            assert src.numel() == dst.numel()
+            x.copy_src, x.copy_dst, x.copy_count = src.data_ptr(), dst.data_ptr(), src.numel()
+        if adadelta is not None:
+            a = adadelta
+            for nm in ("p", "sq", "acc"):
+                _vec(a[nm], nm)
+            x.adadelta, x.p, x.sq_avg, x.acc_delta = 1, a["p"].data_ptr(), a["sq"].data_ptr(), a["acc"].data_ptr()
+            x.lr, x.rho, x.eps, x.weight_decay, x.grad_scale = (float(a["lr"]), float(a.get("rho", 0.9)), float(a.get("eps", 1e-6)),
+                                                                float(a.get("weight_decay", 0.0)), float(a.get("grad_scale", 1.0)))
+            extra = a.get("extra_grad")
+            assert len(a["layers"]) == len(problems) + (1 if extra is not None else 0)
+            for L, (w, off_w, off_b, out, inp) in zip(x.layer, a["layers"]):
+                _mat(w, "w_packed")
+                L.w_packed, L.off_w, L.off_b, L.ldp, L.out, L.inp = w.data_ptr(), int(off_w), int(off_b), w.stride(0), int(out), int(inp)
+            if extra is not None:
+                _mat(extra, "extra_grad")
+                x.g_extra, x.ld_extra = extra.data_ptr(), extra.stride(0)
+        if noise is not None:
+            z = noise["next_noise"]
+            x.next_noise, x.noise_rows, x.noise_ld = z.data_ptr(), z.shape[0], z.stride(0)
+            x.noise_cols, x.noise_ones_col = int(noise["noise_cols"]), int(noise["noise_ones_col"])
+            x.seed, x.step_counter = int(noise["seed"]) & 0xFFFFFFFFFFFFFFFF, noise["step_counter"].data_ptr()
+        _lib.check(self.lib.vgan_gemm_grouped_ex(arr, len(problems), ctypes.byref(x), self._stream()), "vgan_gemm_grouped_ex")
 
     def mse_grad(self, target, pred, gscale, part, g):
         """part[ceil(n/4)] (float64) = partial sums of (pred - target)^2; g = gscale * (pred - target)."""

@@ -86,7 +86,8 @@ class FlatParams:
 class NoKLStepEngine:
     def __init__(self, ops, generator, data, batch_size, batches_per_epoch, lr=0.007, weight_decay=0.04, penalty_weight=10.0,
                  seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None,
-                 generator_mode=None, force_exchange=False, mmd_precision=None, center_operand=True, overlap_exchange=None):
+                 generator_mode=None, force_exchange=False, mmd_precision=None, center_operand=True, overlap_exchange=None,
+                 fuse_update=None):
         self.ops = ops
         self.dev = data.device
         self.rank, self.world, self.group = rank, world, group
@@ -111,6 +112,8 @@ class NoKLStepEngine:
         self.mode = generator_mode or os.environ.get("VGAN_GENERATOR", "collapsed")
         if self.mode not in ("collapsed", "layered"):
             raise ValueError(f"generator_mode must be 'collapsed' or 'layered', got {self.mode!r}")
+        # collapsed mode: Adadelta in the epilogue of the last chain launch (VGAN_FUSE_UPDATE=0: separate optimiser launch)
+        self.fuse_update = (os.environ.get("VGAN_FUSE_UPDATE", "1") == "1") if fuse_update is None else bool(fuse_update)
 
         lin = [m for m in generator.main if isinstance(m, torch.nn.Linear)]
         assert len(lin) == 4
@@ -155,6 +158,7 @@ class NoKLStepEngine:
             # product away from At_2, so the chain is 3 + 2 dependent launches instead of 4 + 3 (each ~5 us whatever its size)
             self.B3 = torch.zeros(e[4], e[2], **f32)
             self.B2 = torch.zeros(e[4], e[1], **f32)
+            self.At1s = torch.zeros(e[1], e[0], **f32)  # snapshot of Wt_1 for the launch that also updates it (fuse_update)
             pmap = torch.full((self.fp.total,), -1, dtype=torch.int32)
             for k in range(1, 5):
                 wk, wk1 = self.widths[k], self.widths[k - 1]
@@ -230,7 +234,9 @@ class NoKLStepEngine:
         # [XY and YY tiles | XX tiles]: the step's Gram launch covers the first part, the overlapped launch the second, and
         # the step tail folds both (one table, one partial buffer).
         self.overlap = self.exchange if overlap_exchange is None else (bool(overlap_exchange) and self.exchange)
-        self._side = torch.cuda.Stream(device=self.dev) if (self.overlap and data.is_cuda) else None
+        # (overlap_exchange="serial": the overlapped schedule's launches on ONE stream -- a measurement aid that separates the
+        # price of the extra launches from the price of the cross-stream edges)
+        self._side = torch.cuda.Stream(device=self.dev) if (self.overlap and data.is_cuda and overlap_exchange != "serial") else None
         if self.overlap:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
         else:
@@ -382,11 +388,25 @@ class NoKLStepEngine:
         M, Gt, At = self.M, self.Gt, self.At
         # (launches are kept homogeneous -- long contractions in one, short ones in the other -- so that the library can run
         # the long-K group on its 16-wave tiles)
-        ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])])
-        ops.gemm_grouped([("NT", M[4], At[3], Gt[4]), ("NT", M[3], At[2], Gt[3]), ("NT", M[2], At[1], Gt[2])])
         fused_noise = dict(next_noise=self.za, noise_cols=self.L, noise_ones_col=self.L, seed=self.seed,
                            step_counter=self.step_counter) if self.noise_mode == "device" else {}
-        ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
+        if not self.fuse_update:
+            ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])])
+            ops.gemm_grouped([("NT", M[4], At[3], Gt[4]), ("NT", M[3], At[2], Gt[3]), ("NT", M[2], At[1], Gt[2])])
+            ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
+            return
+        # The optimiser rides in the LAST product launch of the step: Gt_4, Gt_3, Gt_2 are updated in the epilogue of the tile
+        # that produces them (flat parameter, Adadelta state and packed weight Wt_k in place), Gt_1 = M_1 (complete after the
+        # launch before) by surplus workgroups, and the next step's noise draw rides along too -- no separate optimiser
+        # launch.  Wt_1 is also an OPERAND of that launch (At_1 = Wt_1 in Gt_2 = M_2 . At_1^T), so the launch before it
+        # snapshots it (a copy job riding there) and the product reads the snapshot.
+        ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])],
+                         copy=(self.Wt[1], self.At1s))
+        w, off = self.widths, self.fp.offsets
+        layers = [(self.Wt[k], off[2 * (k - 1)], off[2 * (k - 1) + 1], w[k], w[k - 1]) for k in (4, 3, 2, 1)]
+        ops.gemm_grouped([("NT", M[4], At[3], Gt[4]), ("NT", M[3], At[2], Gt[3]), ("NT", M[2], self.At1s, Gt[2])],
+                         adadelta=dict(p=self.fp.flat, sq=self.fp.sq, acc=self.fp.acc, layers=layers, extra_grad=Gt[1], **adadelta),
+                         noise=fused_noise or None)
 
     # ---- the step -----------------------------------------------------------------------------------
     def _collect(self):
