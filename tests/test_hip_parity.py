@@ -1126,6 +1126,51 @@ def test_kl_step_engine_hip_vs_cpu_provider(ops, n, d):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
 
 
+def test_kl_step_engine_c3_size_vs_port(ops):
+    """VGAN.fit's step engine at the metric's size (d=784, batch=1024, L=49) against oracle/torch_port.PortKL -- the op-for-op
+    autograd port of the reference's two step bodies, pinned to the reference's own run by fixture f4
+    (tests/test_oracle_golden.py) -- on identical parameters, batches and noise: two detector steps with the encoder still
+    trainable, one generator-phase step (which freezes the detector), one detector step with the encoder frozen.  Every step's
+    MMD term and squared-error terms, the bandwidth, and all sixteen detector tensors at the end."""
+    from oracle import torch_port as port
+    from vgan_amd.kl_trainer import KLStepEngine
+    from vgan_amd.modules import Decoder, Detector, Encoder, Generator_big
+    n, d = 1024, 784
+    L = orc.latent_size(d)
+    rng = np.random.default_rng(77)
+    data = orc.synthetic_dataset("c3", rows=4 * n)
+    gen_params = orc.synthetic_generator_params(d, seed=9)      # well-separated softmax: threshold ties are rare
+    gen, det = Generator_big(L, d), Detector(L, d, Encoder, Decoder)
+    with torch.no_grad():
+        for q, v in zip(gen.parameters(), gen_params):
+            q.copy_(torch.as_tensor(v))
+        for q in det.parameters():                               # the reference's weights_init: N(0, 0.1) weights, zero bias
+            q.copy_(torch.as_tensor(rng.normal(0.0, 0.1, size=tuple(q.shape)).astype(np.float32)) if q.dim() == 2 else torch.zeros_like(q))
+    det_params = [q.detach().numpy().copy() for q in det.parameters()]
+    tr = port.PortKL(gen_params, det_params, lr_D=0.007, weight_decay=0.04, weight=10.0)
+    eng = KLStepEngine(ops, gen.cuda(), det.cuda(), dev(data), n, 0.007, 0.04, 10.0)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    for kind, enc_train in (("d", True), ("d", True), ("g", False), ("d", False)):
+        idx = rng.permutation(4 * n)[:n]
+        z = rng.normal(size=(n, L)).astype(np.float32)
+        X, zt = torch.as_tensor(data[idx]), torch.as_tensor(z)
+        if kind == "d":
+            eng.detector_step(torch.as_tensor(idx), zt, train_encoder=enc_train)
+            _, want_mmd, want_mse = tr.detector_step(X, zt)
+        else:
+            eng.generator_phase_step(torch.as_tensor(idx), zt)
+            want_mmd, want_mse = tr.generator_phase_step(X, zt), None
+        got_mmd, got_mse = eng.epoch_sums()
+        ties = int(((host(eng.S) >= np.float32(1.0 / d)) != (tr.subspaces(zt).numpy() == 1.0)).sum())
+        assert ties <= 8, ties
+        assert abs(got_mmd - want_mmd) < 1e-4, (kind, enc_train, got_mmd, want_mmd)
+        if want_mse is not None:
+            np.testing.assert_allclose(got_mse, want_mse, rtol=1e-4)
+    np.testing.assert_allclose(float(eng.bw), float(tr.kernel.bandwidth), rtol=1e-5)
+    for q, ref in zip(det.parameters(), tr.det):
+        np.testing.assert_allclose(host(q), ref.detach().numpy(), rtol=0, atol=2e-5)
+
+
 @pytest.mark.parametrize("centred", [False, True])
 @pytest.mark.parametrize("n,d", [(1024, 784), (264, 1024), (72, 20), (128, 100)])
 def test_mask_project_forward_bf3_equals_two_launches(ops, n, d, centred):

@@ -71,6 +71,26 @@ def test_engine_two_steps_vs_reference_fixture(cfg, mode):
     np.testing.assert_allclose(float(eng.bw), float(g["bw"]), rtol=1e-5)
 
 
+def test_engine_fused_update_path_equals_separate_optimiser_launch():
+    """fuse_update=True (Adadelta in the epilogue of the last chain launch, vgan_gemm_grouped_ex) against the default separate
+    optimiser launch, on the CPU provider: same losses and parameters over three steps of fixture f2 (c2)."""
+    g = load_golden("f2_step_c2.npz")
+    res = {}
+    for fused in (False, True):
+        eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], 512, 1, fuse_update=fused)
+        assert eng.fuse_update == fused
+        eng.set_epoch_batches(torch.arange(512).view(1, 512))
+        losses = []
+        for _ in range(3):
+            eng.set_noise(torch.as_tensor(g["noise"]))
+            eng.step()
+            losses.append(float(eng.loss))
+        res[fused] = (losses, eng.fp.flat.clone(), eng.Wt_all.clone())
+    assert res[True][0] == res[False][0]
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert torch.equal(a, b)
+
+
 def test_engine_bf16x3_precision_mode_vs_reference_fixture():
     """Split-bf16 MMD mode (emulated on the CPU stand-in with torch.bfloat16 roundings): the step still meets the loss bar."""
     g = load_golden("f2_step_c2.npz")

@@ -138,3 +138,35 @@ def test_f6_reference_saved_checkpoint_loads_weights_only():
     masks = orc.NoKLTrainer(params).masks(g["mask_noise"])
     assert np.array_equal(masks, g["masks"])
     assert list(g["files"]) == ["models", "params.csv", "train_history", "train_history.pdf"]
+
+
+def test_f4_port_kl_reproduces_reference_vgan_fit():
+    """oracle/torch_port.PortKL (the op-for-op port of VGAN.fit's two step bodies) replayed on the batches and noise the
+    reference's own 12-epoch run recorded (fixture f4; epoch 0 and 6 detector, the others generator phases): every step's MMD
+    term, both epoch histories, the bandwidth, the final detector parameters and their requires_grad flags."""
+    g = load_golden("f4_kl_c1.npz")
+    data = g["data"]
+    tr = port.PortKL([g[f"gen0_{i}"] for i in range(8)], [g[f"det0_{i}"] for i in range(16)], weight=0.0)
+    nb = 10
+    det_hist, gen_hist, mmds = [], [], []
+    det_loss = gen_loss = np.nan
+    for epoch in range(12):
+        steps = range(epoch * nb, (epoch + 1) * nb)
+        if epoch % 6 == 0:
+            out = [tr.detector_step(torch.as_tensor(data[g["idx"][t]]), torch.as_tensor(g["noise"][t])) for t in steps]
+            det_loss = sum(o[0] for o in out) / nb
+            mmds += [o[1] for o in out]
+        else:
+            out = [tr.generator_phase_step(torch.as_tensor(data[g["idx"][t]]), torch.as_tensor(g["noise"][t])) for t in steps]
+            gen_loss = sum(out) / nb
+            mmds += out
+        det_hist.append(det_loss)
+        gen_hist.append(gen_loss)
+    np.testing.assert_allclose(mmds, g["losses"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(det_hist, g["detector_loss"], rtol=0, atol=2e-6)
+    assert np.isnan(gen_hist[0]) and np.isnan(g["generator_loss"][0])
+    np.testing.assert_allclose(gen_hist[1:], g["generator_loss"][1:], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(float(tr.kernel.bandwidth), float(g["bw"]), rtol=1e-6)
+    for i, q in enumerate(tr.det):
+        np.testing.assert_allclose(q.detach().numpy(), g[f"detT_{i}"], rtol=0, atol=1e-6)
+        assert bool(q.requires_grad) == bool(g[f"detT_rg_{i}"])

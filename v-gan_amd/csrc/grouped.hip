@@ -48,6 +48,42 @@ __device__ __forceinline__ void adadelta_packed_element(const GroupedExtras& x, 
     L.w_packed[(long)row * L.ldp + col] = pv;
 }
 
+// The same for the NE elements a lane holds of an output tile (one column, NE rows), in two phases: the optimiser state is
+// REQUESTED before the product's main loop (it does not depend on the product; requested after it the launch pays one more
+// memory latency per tile -- measured 11.5 us for the launch instead of the product's ~6) and ALL loads precede the first store
+// (the pointers may alias as far as the compiler knows: element-by-element code serialises NE round trips, 16.2 us).
+template <int NE>
+struct AdadeltaTile {
+    long idx[NE];
+    float pv[NE], v[NE], a[NE];
+    bool ok[NE];
+    template <typename RowOf>
+    __device__ __forceinline__ void prefetch(const GroupedExtras& x, const vgan_adadelta_layer& L, int col, RowOf row_of) {
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            const int row = row_of(r);
+            ok[r] = row < L.out && col <= L.in;
+            idx[r] = ok[r] ? (col < L.in ? L.off_w + (long)row * L.in + col : L.off_b + row) : L.off_w;  // clamped: unconditional loads
+            pv[r] = x.p[idx[r]];
+            v[r] = x.sq[idx[r]];
+            a[r] = x.acc[idx[r]];
+        }
+    }
+    template <typename RowOf>
+    __device__ __forceinline__ void finish(const GroupedExtras& x, const vgan_adadelta_layer& L, int col, const float (&g)[NE], RowOf row_of) {
+#pragma unroll
+        for (int r = 0; r < NE; ++r) adadelta_one(pv[r], g[r], v[r], a[r], x.lr, x.rho, x.eps, x.wd, x.gs);
+#pragma unroll
+        for (int r = 0; r < NE; ++r)
+            if (ok[r]) {
+                x.p[idx[r]] = pv[r];
+                x.sq[idx[r]] = v[r];
+                x.acc[idx[r]] = a[r];
+                L.w_packed[(long)row_of(r) * L.ldp + col] = pv[r];
+            }
+    }
+};
+
 // workgroups past the product tiles: copy | element-wise layer | noise (block-uniform dispatch)
 __device__ __forceinline__ void grouped_extra_jobs(const GroupedExtras& x, int b, int layer_index) {
     if (b < x.copy_blocks) {
@@ -73,17 +109,23 @@ __device__ __forceinline__ void tile64(const vgan_gemm_problem& q, int t, float*
     using G = GemmTile<QBM, QBM, QBK, LA, LB, VEC>;
     const int gx = (q.n + QBM - 1) / QBM;
     const int m0 = (t / gx) * QBM, n0 = (t % gx) * QBM;
+    const int col = n0 + G::sub_col(0);
+    auto row_of = [&](int r) { return m0 + G::sub_row(0, r); };
+    AdadeltaTile<EPI ? 16 : 1> upd;
+    if constexpr (EPI) upd.prefetch(x, x.layer[qi], col, row_of);
     f32x16 acc[1][1];
     zero_acc(acc);
     G::template run<false>(q.a, q.lda, q.b, q.ldb, m0, n0, q.m, q.n, q.k, lds, nullptr, acc);
-    const int col = n0 + G::sub_col(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + G::sub_row(0, r);
-        if (row < q.m && col < q.n) {
-            q.c[(long)row * q.ldc + col] = acc[0][0][r];
-            if constexpr (EPI) adadelta_packed_element(x, x.layer[qi], row, col, acc[0][0][r]);
-        }
+        if (row < q.m && col < q.n) q.c[(long)row * q.ldc + col] = acc[0][0][r];
+    }
+    if constexpr (EPI) {
+        float g[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = acc[0][0][r];
+        upd.finish(x, x.layer[qi], col, g, row_of);
     }
 }
 
@@ -92,17 +134,18 @@ __device__ __forceinline__ void tile_ks(const vgan_gemm_problem& q, int t, float
     using G = GemmTileKS<QKS, LA, LB, VEC, NW>;
     const int gx = (q.n + 31) / 32;
     const int m0 = (t / gx) * 32, n0 = (t % gx) * 32;
+    const int col = n0 + G::col_of();
+    auto row_of = [&](int rr) { return m0 + G::row_of(rr); };
+    AdadeltaTile<EPI ? G::NR : 1> upd;
+    if constexpr (EPI) upd.prefetch(x, x.layer[qi], col, row_of);
     float o[G::NR];
     G::run(q.a, q.lda, q.b, q.ldb, m0, n0, q.m, q.n, q.k, lds, o);
-    const int col = n0 + G::col_of();
 #pragma unroll
     for (int rr = 0; rr < G::NR; ++rr) {
         const int row = m0 + G::row_of(rr);
-        if (row < q.m && col < q.n) {
-            q.c[(long)row * q.ldc + col] = o[rr];
-            if constexpr (EPI) adadelta_packed_element(x, x.layer[qi], row, col, o[rr]);
-        }
+        if (row < q.m && col < q.n) q.c[(long)row * q.ldc + col] = o[rr];
     }
+    if constexpr (EPI) upd.finish(x, x.layer[qi], col, o, row_of);
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }

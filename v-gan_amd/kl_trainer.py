@@ -105,6 +105,10 @@ class KLStepEngine:
         f32 = dict(dtype=torch.float32, device=self.dev)
 
         self.gen = [m for m in generator.main if isinstance(m, torch.nn.Linear)]
+        # The generator never trains in VGAN.fit (module docstring): its four bias-Linear layers are collapsed ONCE into
+        # logits = [z|1] . Gt_4..Gt_1^T -- one product per step instead of four.
+        self.gfp = FlatParams([q for m in self.gen for q in (m.weight, m.bias)], self.dev)
+        self.G = CollapsedChain(ops, self.gfp, 0, self.dev)
         enc = [m for m in detector.encoder.main if isinstance(m, torch.nn.Linear)]
         dec = [m for m in detector.decoder.main if isinstance(m, torch.nn.Linear)]
         assert len(self.gen) == 4 and len(enc) == 4 and len(dec) == 4
@@ -121,8 +125,10 @@ class KLStepEngine:
         self.eD = eD
 
         # generator forward (no gradient)
-        self.z = torch.zeros(n, L, **f32)
-        self.gact = [self.z] + [torch.zeros(n, m.out_features, **f32) for m in self.gen]
+        self.zh = torch.zeros(n, self.G.e[0], **f32)         # [z | 1 | 0-pad]
+        self.zh[:, L] = 1.0
+        self.z = self.zh[:, :L]
+        self.logits = torch.zeros(n, d, **f32)
         self.S = torch.zeros(n, d, **f32)
         self.U = torch.zeros(n, d, **f32)
         self.perm = torch.zeros(1, n, dtype=torch.int32, device=self.dev)
@@ -139,7 +145,12 @@ class KLStepEngine:
         self.denc = torch.zeros(1 + self.msplits, 2 * n, eD, **f32)
         self.mse_part = torch.zeros((2 * n + 3) // 4, dtype=torch.float64, device=self.dev)
         # MMD on the encodings (gradient for all 2n rows)
+        # the MMD operand: the L encoding columns copied into a zero-padded [2n, round4(L)] image (norms in the same pass), so
+        # that p = L = 49 runs the 16-byte staging path of the Gram / backward kernels
+        self.pz = _round4(L)
+        self.encZ = torch.zeros(2 * n, self.pz, **f32)
         self.sq = torch.zeros(2 * n, **f32)
+        self._fin = None
         self.tiles = ops.build_tiles(n, 2, device=self.dev)
         self.tiles0 = ops.build_tiles(n, 0, device=self.dev)
         self.partial = torch.zeros(max(self.tiles.shape[0], self.tiles0.shape[0]), 4, **f32)
@@ -184,31 +195,41 @@ class KLStepEngine:
             self.graphs[key] = g
         g.replay()
 
-    def _forward(self, want_grad):
+    def _finalize_job(self, tiles):
+        return self.ops.finalize_job(self.partial, tiles, self.colpart, self.ops.colmax_chunks(self.n), self.colkey, self.n, self.d,
+                                     self.pen, self.stats, self.mmd, self.acc_mmd, 1.0, None)
+
+    def _forward(self, want_grad, want_decoder=True):
+        """Returns True when the step tail (block sums -> loss) is still to be done by the caller (it rides in the MMD backward
+        launch when there is one)."""
         ops, n, d, L = self.ops, self.n, self.d, self.L
-        for k, m in enumerate(self.gen):
-            ops.linear_forward(self.gact[k], m.weight.detach(), m.bias.detach(), self.gact[k + 1])
-        ops.mask_project_forward(self.gact[4], self.data, self.perm, self.S, self.U, self.XPh[:n], self.XPh[n:], self.sqxp[:n],
+        self.G.forward(self.zh, self.logits)
+        ops.mask_project_forward(self.logits, self.data, self.perm, self.S, self.U, self.XPh[:n], self.XPh[n:], self.sqxp[:n],
                                  self.sqxp[n:])
         self.E.forward(self.XPh, self.encH[:, :L])
-        self.D.forward(self.encH, self.dec[:, :d])
-        Z, p = self.encH, self.p
-        ops.row_sqnorm(Z, self.sq, p)
+        if want_decoder:
+            self.D.forward(self.encH, self.dec[:, :d])
+        Z, p = self.encZ, self.pz
+        ops.gather_rows_split(self.encH[:, :L], None, None, Z, self.sq, n=2 * n)  # copy + norms; pad columns of Z stay zero
         if not self.has_bw:  # first call of the (process-wide) RBF calibrates its bandwidth (Mmd_loss_constrained.py:16-20)
             ops.mmd_gram(Z, self.sq, n, p, None, self.tiles0, True, None, 0, self.partial)
             ops.mmd_reduce(self.partial, self.tiles0, self.stats, True)
             ops.mmd_set_bandwidth(self.stats, n, self.bw)
             self.has_bw = True
         tiles = self.tiles if want_grad else self.tiles0
-        ops.mmd_gram(Z, self.sq, n, p, self.bw, tiles, False, self.Wg if want_grad else None, 0, self.partial)
-        ops.mmd_reduce(self.partial, tiles, self.stats, True)
-        ops.colmax(self.S, 0, self.colpart, self.colkey, True)
-        ops.mmd_loss(self.stats, self.colkey, n, d, self.pen, self.mmd, self.acc_mmd, 1.0, None)
+        # Gram + the column arg-max cells of topk(U, 1, 0) in one launch; the tail (block sums, arg-max keys, loss) in one more,
+        # or inside the MMD backward launch when the encoder trains
+        ops.mmd_gram_colmax(Z, self.sq, n, p, self.bw, tiles, self.Wg if want_grad else None, 0, self.partial, self.S, 0, self.colpart, True)
+        if want_grad:
+            return True
+        ops.mmd_finalize(self.partial, tiles, self.colpart, ops.colmax_chunks(n), self.colkey, n, d, self.pen, self.stats, self.mmd,
+                         self.acc_mmd, 1.0, None)
+        return False
 
     def generator_phase_step(self, idx, noise):
         """Loss evaluation of the generator phase: accumulates MMD(enc_X, enc_P, U) (src/vgan.py:295-329)."""
         self._feed(idx, noise)
-        self._run("g", lambda: self._forward(want_grad=False))
+        self._run("g", lambda: self._forward(want_grad=False, want_decoder=False))  # loss_G needs no decoder pass
 
     def detector_step(self, idx, noise, train_encoder):
         self._feed(idx, noise)
@@ -217,7 +238,7 @@ class KLStepEngine:
     def _detector_body(self, train_encoder):
         ops, n, d, L = self.ops, self.n, self.d, self.L
         # the MMD term reaches only the encoder: with the encoder frozen neither its gradient weights nor its backward run
-        self._forward(want_grad=train_encoder)
+        tail_pending = self._forward(want_grad=train_encoder)
         # gradients of G = MMD - 0.1 mse_X - 0.1 mse_P  (= -loss_D)
         gs = -0.1 * 2.0 / (float(n) * d)
         # both squared-error terms have the same weight and the same 1/(n d): one pass over the 2n stacked rows, one fold
@@ -226,7 +247,10 @@ class KLStepEngine:
         adadelta = dict(lr=self.lr, rho=ADADELTA_RHO, eps=ADADELTA_EPS, weight_decay=self.wd, grad_scale=-1.0)
         if train_encoder:  # both read the CURRENT decoder products: before the decoder update
             self.D.input_grad(self.ddec, self.denc[0][:, :L])  # columns >= L of every slab stay zero
-            ops.mmd_backward(self.Wg, self.encH, 0, 2 * n, 2 * n, self.p, None, self.denc[1], self.msplits, 2 * n * self.eD)
+            if self._fin is None:
+                self._fin = self._finalize_job(self.tiles)
+            ops.mmd_backward(self.Wg, self.encZ, 0, 2 * n, 2 * n, self.pz, None, self.denc[1], self.msplits, 2 * n * self.eD,
+                             self._fin if tail_pending else None)
         self.D.backward(self.ddec, self.encH)
         self.D.update(**adadelta)
         if train_encoder:
