@@ -114,18 +114,40 @@ def kernel_rooflines(eng):
     # the fp32 kernels work on 64-wide tiles: their own table when the engine runs the 128-wide bf16x3 Gram
     tiles64 = eng.tiles if eng.gram_tile == 64 else ops.build_tiles(n, 1, eng.rank, eng.world, device=eng.Z.device)
     part64 = torch.zeros(tiles64.shape[0], 4, device=eng.Z.device)
-    add("mmd_gram_kernel<4,false,1>", time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, tiles64, False, Wg, n + lo, part64)))
+    # the Gram launch as the step issues it: XY and YY tiles only when the X-X tiles run on the side stream (trainer.py); its
+    # algorithmic flop = the pairs it covers x 2 d: n^2 (XY) + n (n + 1) / 2 (YY upper triangle); row-sharded: 2 nl n
+    pairs = (n * n + n * (n + 1) / 2) if eng.world == 1 else 2.0 * nl * n
+    main_flop = 2.0 * D_FEAT * pairs if eng.overlap else flop
+    if eng.gram_tile == 64 and eng.overlap:
+        tiles64 = eng.tiles[:eng.n_main]
+    ms = time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, tiles64, False, Wg, n + lo, part64))
+    out["mmd_gram_kernel<4,false,1>"] = {"ms": ms, "tflops": (main_flop if eng.gram_tile == 64 else flop) / (ms * 1e-3) / 1e12,
+                                         "flop": main_flop if eng.gram_tile == 64 else flop, "tiles": int(tiles64.shape[0])}
     add("mmd_backward_kernel<4,2>", time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU,
                                                                              mul_shift=eng.center)))
     if eng.bf3:
         gs = nl * eng.dp
         gname = "mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"
-        add(gname, time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles, eng.Wh, eng.Wl, n + lo, eng.partial,
-                                                        tile=eng.gram_tile)))
+        # as the step launches it: the XY and YY tiles (the X-X tiles run in a side-stream launch of their own, see trainer.py);
+        # algorithmic flop of the pairs THIS launch covers: n^2 (XY) + n (n + 1) / 2 (YY upper triangle) pairs x 2 d
+        # (row-sharded: nl n + nl n pairs, no symmetry across ranks)
+        ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[:eng.n_main], eng.Wh, eng.Wl, n + lo, eng.partial,
+                                                  tile=eng.gram_tile))
+        out[gname] = {"ms": ms, "tflops": main_flop / (ms * 1e-3) / 1e12, "flop": main_flop, "tiles": int(eng.n_main)}
+        if eng.overlap and eng.tiles.shape[0] > eng.n_main:
+            xx_flop = flop - main_flop
+            ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[eng.n_main:], None, None, 0,
+                                                      eng.partial[eng.n_main:], tile=eng.gram_tile))
+            out[gname + " [X-X tiles, side stream]"] = {"ms": ms, "tflops": xx_flop / (ms * 1e-3) / 1e12, "flop": xx_flop,
+                                                        "tiles": int(eng.tiles.shape[0] - eng.n_main)}
         big_bwd = ops.mmd_backward_bf3_tile(nl, d, eng.bsplits, eng.bwd_tile) == 128  # the library's own choice
-        add("mmd_backward_bf3_big_kernel" if big_bwd else "mmd_backward_bf3_kernel<64>", time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d,
-                                                                                 eng.Z[lo:lo + nl], eng.gU, eng.bsplits, gs,
-                                                                                 mul_shift=eng.center, tile=eng.bwd_tile)))
+        bname = "mmd_backward_bf3_big_kernel" if big_bwd else "mmd_backward_bf3_kernel<64>"
+        if eng.rm_backward:  # B operand = the Gram's row-major images (transposed LDS reads)
+            add(bname, time_kernel(lambda: ops.mmd_backward_bf3_rm(eng.Wh, eng.Wl, eng.Zh, eng.Zl, 2 * n, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl],
+                                                                     eng.gU, eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile)))
+        else:
+            add(bname, time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl], eng.gU,
+                                                                  eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile)))
         out["bf3_prepare_kernel"] = {"ms": time_kernel(lambda: ops.mmd_bf3_prepare(eng.Z, 2 * n, d, eng.Zh, eng.Zl, eng.ZTh, eng.ZTl))}
     return out
 

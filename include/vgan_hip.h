@@ -249,6 +249,15 @@ int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const
                           int p, const float* mul, int ldmul, const float* mul_shift, float* out, int ldo,
                           int splits, int64_t slab_stride, int tile, const vgan_finalize_job* finalize,
                           vgan_stream_t stream);
+/* The same backward product reading Z's ROW-MAJOR split images Zh, Zl [zrows, kp] -- the ones vgan_mmd_gram_bf3 reads -- so
+ * that no transposed copy of Z has to be produced: the B fragments (8 consecutive contraction indices per lane) come out of a
+ * row-major LDS image through ds_read_b64_tr_b16.  kn = the padded contraction length (columns of Wh / Wl, a multiple of 64,
+ * >= zrows; columns >= zrows of W must be zero).  Everything else as vgan_mmd_backward_bf3. */
+int vgan_mmd_backward_bf3_rm(const uint16_t* Wh, const uint16_t* Wl, int ldw, int kn, const uint16_t* Zh,
+                             const uint16_t* Zl, int kp, int zrows, const float* Z, int ldz, int wrow0, int nr,
+                             int p, const float* mul, int ldmul, const float* mul_shift, float* out, int ldo,
+                             int splits, int64_t slab_stride, int tile, const vgan_finalize_job* finalize,
+                             vgan_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * Grouped small products: up to VGAN_GEMM_MAX_GROUP independent row-major GEMMs in one launch.
  * Generator_big (src/models/Generator.py:61-66) has no activation between its Linear layers, so its
@@ -306,7 +315,8 @@ int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count, const vga
  * batch rows it writes S [n, d], Z = [X ; U*X] ([2n, ldz] fp32), sq [2n] and the split images Zh, Zl [2n, kp],
  * ZTh, ZTl [kp, kn] of Z (pad regions are not touched: pre-zeroed by the caller).  Shape contract: d % 4 == 0,
  * d <= 1024, n % 8 == 0, leading dimensions % 4 == 0, 16-byte aligned bases; otherwise use the two calls
- * (with norm_split = 1).  center as in vgan_mask_project_forward; sq holds the norms of the split values. */
+ * (with norm_split = 1).  center as in vgan_mask_project_forward; sq holds the norms of the split values.
+ * ZTh / ZTl may both be NULL (callers of vgan_mmd_backward_bf3_rm need no transposed images). */
 int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                   const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z,
                                   int ldz, float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,

@@ -351,6 +351,14 @@ class CpuOps:
             r = r * (_np(mul)[:nr, :p] + (_np(mul_shift)[:p] if mul_shift is not None else 0.0))
         out[:nr, :p].copy_(torch.as_tensor(r))
 
+    def mmd_backward_bf3_rm(self, Wh, Wl, Zh, Zl, zrows, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
+                            tile=0):
+        kn = (int(zrows) + 63) // 64 * 64
+        ZTh = torch.zeros(Zh.shape[1], kn, dtype=torch.int16)
+        ZTl = torch.zeros(Zh.shape[1], kn, dtype=torch.int16)
+        ZTh[:, :zrows], ZTl[:, :zrows] = Zh[:zrows].t(), Zl[:zrows].t()
+        self.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits, slab_stride, finalize, mul_shift, tile)
+
     def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
         return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 

@@ -648,6 +648,44 @@ def test_bf3_prepare_and_kernels_vs_fp64(ops):
         np.testing.assert_allclose(host(slabs.sum(0)), host(out), rtol=0, atol=1e-5 * float(out.abs().max()) + 1e-9)
 
 
+@pytest.mark.parametrize("n,d,nr_of,tile,splits", [(1024, 784, 1, 0, 2), (300, 130, 1, 64, 1), (250, 901, 2, 64, 3), (512, 1000, 1, 128, 2),
+                                                    (192, 200, 2, 128, 1)])
+def test_backward_bf3_rowmajor_operand_equals_transposed_operand(ops, n, d, nr_of, tile, splits):
+    """vgan_mmd_backward_bf3_rm (B fragments out of Z's ROW-MAJOR split images by ds_read_b64_tr_b16) against
+    vgan_mmd_backward_bf3 on the transposed copies of the same images: the same products in the same order, so the outputs
+    must be bit-identical -- 64- and 128-wide tiles, ragged row counts, feature counts that are no multiple of the tile,
+    split-K slabs, gradient rows for the Y half or for all rows, multiplier with shift."""
+    rng = np.random.default_rng(n + d)
+    N = 2 * n
+    kp, kn = (d + 63) // 64 * 64, (N + 63) // 64 * 64
+    dp = (d + 3) // 4 * 4
+    Z = torch.zeros(N, dp, device="cuda")
+    Z[:, :d] = dev(rng.normal(size=(N, d)).astype(np.float32))
+    i16 = dict(dtype=torch.int16, device="cuda")
+    Zh, Zl, ZTh, ZTl = torch.zeros(N, kp, **i16), torch.zeros(N, kp, **i16), torch.zeros(kp, kn, **i16), torch.zeros(kp, kn, **i16)
+    ops.mmd_bf3_prepare(Z, N, d, Zh, Zl, ZTh, ZTl)
+    nr, wrow0 = (n, n) if nr_of == 1 else (N, 0)
+    W = (rng.normal(size=(nr, N)) * 1e-3).astype(np.float32)
+    Wt = dev(W)
+    Wh, Wl = torch.zeros(nr, kn, **i16), torch.zeros(nr, kn, **i16)
+    hi = Wt.to(torch.bfloat16)
+    Wh[:, :N] = hi.view(torch.int16)
+    Wl[:, :N] = (Wt - hi.float()).to(torch.bfloat16).view(torch.int16)
+    mul = dev(rng.normal(size=(nr, dp)).astype(np.float32))
+    shift = dev(rng.normal(size=(dp,)).astype(np.float32))
+    a = torch.full((splits, nr, dp), float("nan"), device="cuda")
+    b = torch.full((splits, nr, dp), float("nan"), device="cuda")
+    ops.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, wrow0, nr, d, mul, a[0], splits, nr * dp, mul_shift=shift, tile=tile)
+    ops.mmd_backward_bf3_rm(Wh, Wl, Zh, Zl, N, Z, wrow0, nr, d, mul, b[0], splits, nr * dp, mul_shift=shift, tile=tile)
+    torch.cuda.synchronize()
+    assert torch.equal(a[:, :, :d], b[:, :, :d])
+    w64 = (Wh.view(torch.bfloat16).double() + Wl.view(torch.bfloat16).double())[:, :N]
+    z64 = (Zh.view(torch.bfloat16).double() + Zl.view(torch.bfloat16).double())[:, :d]
+    want = 2.0 * (w64.sum(1, keepdim=True) * Z[wrow0:wrow0 + nr, :d].double() - w64 @ z64) * (mul[:, :d].double() + shift[:d].double())
+    got = b.sum(0)[:, :d].double()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("mode", ["collapsed"])
 def test_c3_step_bf16x3_vs_fp64_reference(ops, mode):
     """The metric configuration in split-bf16 mode: loss within the 1e-4 bar of the reference's fp64 value."""

@@ -296,16 +296,18 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
 }
 
 // ---- backward: out = 2 (rowsum(W) z - W . Z) * mul, W = Wh + Wl [nr, kn], Z^T = ZTh + ZTl [kp, kn] -------------
-template <int BK>
+// RM: the B operand is Z's ROW-MAJOR split images (Zh, Zl [zrows, kp], what the Gram reads) instead of the transposed copies
+// (ZTh, ZTl [kp, kn]); `kn` is then the padded contraction length (columns of W) and `brows` the rows of Zh that exist.
+template <int BK, bool RM>
 __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_kernel(const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                                                     int ldw, const unsigned short* __restrict__ ZTh,
-                                                                    const unsigned short* __restrict__ ZTl, int kn,
+                                                                    const unsigned short* __restrict__ ZTl, int kn, int ldb, int brows,
                                                                     const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                     int ptiles, const float* __restrict__ mul, int ldmul,
                                                                     const float* __restrict__ mul_shift, float* __restrict__ out, int ldo,
                                                                     int kchunk, long slab_stride, vgan_finalize_job job) {
     using G = GemmBF3<BK>;
-    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
+    __shared__ __attribute__((aligned(16))) char lds[RM ? G::kLdsBytesT : G::kLdsBytes];
     __shared__ float rs[64];
     // XCD-aware order as in mmd_backward_kernel: down 4 row panels, then the next feature panel
     const int gx = ptiles, gy = (nr + 63) / 64, total = gx * gy;
@@ -336,7 +338,13 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
         z_pre[r] = Z[(long)(wrow0 + rowc) * ldz + colc];
         m_pre[r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] + mshift : 1.f;
     }
-    if (klen > 0) G::template run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, gx * 64, klen, lds, rs, acc);
+    if (klen > 0) {
+        if constexpr (RM)
+            G::template run_bt<true>(Wh + k0, Wl + k0, ldw, ZTh + (long)k0 * ldb, ZTl + (long)k0 * ldb, ldb, brows - k0, m0, n0, nr, klen, lds,
+                                     rs, acc);
+        else
+            G::template run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, ldb, m0, n0, nr, gx * 64, klen, lds, rs, acc);
+    }
     if (col >= p) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -349,15 +357,16 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
 }
 
 // ---- the backward product on 128x128 tiles (large problems; same decomposition, GemmBF3Big) ---------------------
+template <bool RM>
 __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                                                       int ldw, const unsigned short* __restrict__ ZTh,
-                                                                      const unsigned short* __restrict__ ZTl, int kn,
+                                                                      const unsigned short* __restrict__ ZTl, int kn, int ldb, int brows,
                                                                       const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                       int ptiles, const float* __restrict__ mul, int ldmul,
                                                                       const float* __restrict__ mul_shift, float* __restrict__ out, int ldo,
                                                                       int kchunk, long slab_stride, int nb_rows, vgan_finalize_job job) {
     using G = GemmBF3Big;  // nb_rows: rows of ZT that exist (kp); feature rows past it are clamped, their columns discarded
-    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
+    __shared__ __attribute__((aligned(16))) char lds[RM ? G::kLdsBytesT : G::kLdsBytes];
     __shared__ float rs[128];
     const int gx = ptiles, gy = (nr + 127) / 128, total = gx * gy;
     if ((int)blockIdx.x >= total) {
@@ -390,7 +399,13 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i2][r] = 0.f;
-    if (klen > 0) G::run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, kn, m0, n0, nr, nb_rows, klen, lds, acc, rs);
+    if (klen > 0) {
+        if constexpr (RM)
+            G::template run_bt<true>(Wh + k0, Wl + k0, ldw, ZTh + (long)k0 * ldb, ZTl + (long)k0 * ldb, ldb, nb_rows, brows - k0, m0, n0, nr, klen,
+                                     lds, acc, rs);
+        else
+            G::template run<true>(Wh + k0, Wl + k0, ldw, ZTh + k0, ZTl + k0, ldb, m0, n0, nr, nb_rows, klen, lds, acc, rs);
+    }
     if (col >= p) return;
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
@@ -453,39 +468,60 @@ extern "C" int vgan_mmd_backward_bf3_tile(int nr, int p, int splits, int tile) {
     return big_tiles * splits >= 512 ? 128 : 64;
 }
 
-extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh, const uint16_t* ZTl, int kn,
-                                     int kp, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
-                                     const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
-                                     const vgan_finalize_job* finalize, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(Wh && Wl && ZTh && ZTl && Z && out && nr > 0 && p > 0 && kn > 0 && kn % 64 == 0 && kp >= p && kp % 64 == 0);
+// common launcher of the two operand forms: rm = 0: B = (ZTh, ZTl) [kp, kn] transposed images; rm = 1: B = (Zh, Zl) [zrows, kp]
+static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* Bh, const uint16_t* Bl, int kn, int kp,
+                               int zrows, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
+                               const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
+                               const vgan_finalize_job* finalize, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(Wh && Wl && Bh && Bl && Z && out && nr > 0 && p > 0 && kn > 0 && kn % 64 == 0 && kp >= p && kp % 64 == 0);
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
-    VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(ZTh) && aligned16(ZTl) && ldw % 8 == 0);
+    VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(Bh) && aligned16(Bl) && ldw % 8 == 0);
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
+    VGAN_CHECK_ARG((tile == 0 || tile == 64 || tile == 128) && (mul_shift == nullptr || mul != nullptr) && (!rm || zrows > 0));
     const int kchunk = ((kn / 64 + splits - 1) / splits) * 64;
-    const int big_tiles = ((p + 127) / 128) * ((nr + 127) / 128);
-    VGAN_CHECK_ARG((tile == 0 || tile == 64 || tile == 128) && (mul_shift == nullptr || mul != nullptr));
-    if (vgan_mmd_backward_bf3_tile(nr, p, splits, tile) == 128) {
-        const int pt = (p + 127) / 128;
-        dim3 gridb(big_tiles + (finalize != nullptr ? 1 : 0), splits);
-        vgan_finalize_job jb{};
-        if (finalize != nullptr) {
-            VGAN_CHECK_ARG(finalize_job_ok(*finalize));
-            jb = *finalize;
-        }
-        hipLaunchKernelGGL(mmd_backward_bf3_big_kernel, gridb, dim3(512), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, pt, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, kp, jb);
-        VGAN_CHECK_LAUNCH();
-        return VGAN_OK;
-    }
-    const int ptiles = (p + 63) / 64;
+    const int ldb = rm ? kp : kn;
     vgan_finalize_job job{};
     if (finalize != nullptr) {
         VGAN_CHECK_ARG(finalize_job_ok(*finalize));
         job = *finalize;
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (vgan_mmd_backward_bf3_tile(nr, p, splits, tile) == 128) {
+        const int pt = (p + 127) / 128;
+        dim3 grid(pt * ((nr + 127) / 128) + (finalize != nullptr ? 1 : 0), splits);
+        if (rm)
+            hipLaunchKernelGGL(mmd_backward_bf3_big_kernel<true>, grid, dim3(512), 0, st, Wh, Wl, ldw, Bh, Bl, kn, ldb, zrows, Z, ldz, wrow0, nr,
+                               p, pt, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, kp, job);
+        else
+            hipLaunchKernelGGL(mmd_backward_bf3_big_kernel<false>, grid, dim3(512), 0, st, Wh, Wl, ldw, Bh, Bl, kn, ldb, 0, Z, ldz, wrow0, nr, p,
+                               pt, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, kp, job);
+        VGAN_CHECK_LAUNCH();
+        return VGAN_OK;
+    }
+    const int ptiles = (p + 63) / 64;
     dim3 grid(ptiles * ((nr + 63) / 64) + (finalize != nullptr ? 1 : 0), splits);
-        hipLaunchKernelGGL(mmd_backward_bf3_kernel<64>, grid, dim3(kBlock), 0, (hipStream_t)stream, Wh, Wl, ldw, ZTh, ZTl, kn, Z, ldz, wrow0,
-                           nr, p, ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job);
+    if (rm)
+        hipLaunchKernelGGL((mmd_backward_bf3_kernel<64, true>), grid, dim3(kBlock), 0, st, Wh, Wl, ldw, Bh, Bl, kn, ldb, zrows, Z, ldz, wrow0, nr,
+                           p, ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job);
+    else
+        hipLaunchKernelGGL((mmd_backward_bf3_kernel<64, false>), grid, dim3(kBlock), 0, st, Wh, Wl, ldw, Bh, Bl, kn, ldb, 0, Z, ldz, wrow0, nr, p,
+                           ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
+}
+
+extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh, const uint16_t* ZTl, int kn,
+                                     int kp, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
+                                     const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
+                                     const vgan_finalize_job* finalize, vgan_stream_t stream) {
+    return launch_backward_bf3(0, Wh, Wl, ldw, ZTh, ZTl, kn, kp, 0, Z, ldz, wrow0, nr, p, mul, ldmul, mul_shift, out, ldo, splits, slab_stride,
+                               tile, finalize, stream);
+}
+
+extern "C" int vgan_mmd_backward_bf3_rm(const uint16_t* Wh, const uint16_t* Wl, int ldw, int kn, const uint16_t* Zh, const uint16_t* Zl,
+                                        int kp, int zrows, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
+                                        const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
+                                        const vgan_finalize_job* finalize, vgan_stream_t stream) {
+    return launch_backward_bf3(1, Wh, Wl, ldw, Zh, Zl, kn, kp, zrows, Z, ldz, wrow0, nr, p, mul, ldmul, mul_shift, out, ldo, splits,
+                               slab_stride, tile, finalize, stream);
 }

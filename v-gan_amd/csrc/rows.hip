@@ -241,8 +241,10 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                         const long grow = (long)(im * n + i) * kp + 4 * q;
                         *reinterpret_cast<uint2*>(Zh + grow) = ph;
                         *reinterpret_cast<uint2*>(Zl + grow) = pl;
-                        *reinterpret_cast<uint2*>(tile + ((2 * im) * R + lr) * ldt + 4 * q) = ph;
-                        *reinterpret_cast<uint2*>(tile + ((2 * im + 1) * R + lr) * ldt + 4 * q) = pl;
+                        if (ZTh != nullptr) {
+                            *reinterpret_cast<uint2*>(tile + ((2 * im) * R + lr) * ldt + 4 * q) = ph;
+                            *reinterpret_cast<uint2*>(tile + ((2 * im + 1) * R + lr) * ldt + 4 * q) = pl;
+                        }
                     }
                 }
             }
@@ -252,12 +254,13 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                 sq[i] = nx;
                 sq[n + i] = ny;
             }
-        } else {  // rows past the batch: their tile rows are read by the transposed store below (full 16-byte pieces)
+        } else if (ZTh != nullptr) {  // rows past the batch: their tile rows are read by the transposed store below (full 16-byte pieces)
             for (int c = lane; c < ldt; c += 64)
 #pragma unroll
                 for (int im = 0; im < 4; ++im) tile[(im * R + lr) * ldt + c] = 0;
         }
     }
+    if (ZTh == nullptr) return;  // (uniform) no transposed images wanted: the backward product reads the row-major ones
     __syncthreads();
     // transposed images: features (j, j+1), rows i0 .. i0+7 of image X (columns i0..) and Y (columns n + i0 ..): per image
     // eight 4-byte LDS reads (two features at once) and one 16-byte store per feature
@@ -495,15 +498,16 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
                                              const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z, int ldz,
                                              float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh, uint16_t* ZTl, int kn,
                                              int n, int d, const float* center, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(logits && data && S && Z && sq && Zh && Zl && ZTh && ZTl && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
-    VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && kp >= d && kp % 64 == 0 && kn >= 2 * n && kn % 64 == 0);
+    VGAN_CHECK_ARG(logits && data && S && Z && sq && Zh && Zl && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
+    VGAN_CHECK_ARG((ZTh == nullptr) == (ZTl == nullptr));
+    VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && kp >= d && kp % 64 == 0 && (ZTh == nullptr || (kn >= 2 * n && kn % 64 == 0)));
     // shape contract of the fused path (callers fall back to vgan_mask_project_forward + vgan_mmd_bf3_prepare otherwise)
     VGAN_CHECK_ARG(d % 4 == 0 && d <= 1024 && n % 8 == 0 && ldl % 4 == 0 && ldd % 4 == 0 && ldz % 4 == 0);
     VGAN_CHECK_ARG(aligned16(logits) && aligned16(data) && aligned16(S) && aligned16(Z) && aligned16(Zh) && aligned16(Zl) &&
-                   aligned16(ZTh) && aligned16(ZTl) && (center == nullptr || aligned16(center)));
+                   (ZTh == nullptr || (aligned16(ZTh) && aligned16(ZTl))) && (center == nullptr || aligned16(center)));
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, 0};
     const dim3 grid(8 * ((n / 8 + 7) / 8)), block(512);
-    const size_t shmem = (size_t)4 * 8 * (d + 8) * sizeof(unsigned short);
+    const size_t shmem = ZTh != nullptr ? (size_t)4 * 8 * (d + 8) * sizeof(unsigned short) : 0;
     hipStream_t st = (hipStream_t)stream;
     const int nt = (d / 4 + 63) / 64;
     // (dynamic LDS above 64 KB -- d close to 1024 -- needs the opt-in; setting it is idempotent and cheap)

@@ -75,6 +75,7 @@ SIGNATURES = {
     "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p]),
     "vgan_mmd_backward_bf3_tile": (_i, [_i, _i, _i, _i]),
+    "vgan_mmd_backward_bf3_rm": (_i, [_p, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_noise_normal": (_i, [_p, _i, _i, _i, _i, _u64, _p, _u64, _p]),

@@ -123,7 +123,8 @@ class HipOps:
         n, d = logits.shape
         _lib.check(self.lib.vgan_mask_project_forward_bf3(_ptr(logits), logits.stride(0), _ptr(data), data.stride(0), _ptr(rows),
                                                           _ptr(row_cursor), int(row_batches), int(row_stride), _ptr(S), _ptr(Z), Z.stride(0),
-                                                          _ptr(sq), _ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(ZTh), _ptr(ZTl), ZTh.stride(0),
+                                                          _ptr(sq), _ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(ZTh), _ptr(ZTl),
+                                                          ZTh.stride(0) if ZTh is not None else 0,
                                                           n, d, _ptr(center), self._stream()), "vgan_mask_project_forward_bf3")
 
     @staticmethod
@@ -300,6 +301,19 @@ class HipOps:
                                                   _ptr(mul_shift), _ptr(out), out.stride(0), int(splits), int(slab_stride), int(tile),
                                                   ctypes.byref(finalize) if finalize is not None else None, self._stream()),
                    "vgan_mmd_backward_bf3")
+
+    def mmd_backward_bf3_rm(self, Wh, Wl, Zh, Zl, zrows, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
+                            tile=0):
+        """mmd_backward_bf3 on the ROW-MAJOR split images Zh, Zl [>= zrows, kp] (no transposed copies of Z)."""
+        _mat(Z, "Z"), _mat(out, "out")
+        ldmul = mul.stride(0) if mul is not None else 0
+        kn = (int(zrows) + 63) // 64 * 64
+        assert Wh.stride(0) >= kn and Zh.shape[0] >= zrows
+        _lib.check(self.lib.vgan_mmd_backward_bf3_rm(_ptr(Wh), _ptr(Wl), Wh.stride(0), kn, _ptr(Zh), _ptr(Zl), Zh.stride(0), int(zrows),
+                                                     _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul, _ptr(mul_shift),
+                                                     _ptr(out), out.stride(0), int(splits), int(slab_stride), int(tile),
+                                                     ctypes.byref(finalize) if finalize is not None else None, self._stream()),
+                   "vgan_mmd_backward_bf3_rm")
 
     def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
         """Tile edge (64 / 128) mmd_backward_bf3 runs for this shape (host-side query of the library's rule)."""

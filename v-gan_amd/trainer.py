@@ -219,7 +219,14 @@ class NoKLStepEngine:
             i16 = dict(dtype=torch.int16, device=self.dev)
             self.kp, self.kn = (d + 63) // 64 * 64, (2 * n + 63) // 64 * 64
             self.Zh, self.Zl = torch.zeros(2 * n, self.kp, **i16), torch.zeros(2 * n, self.kp, **i16)
-            self.ZTh, self.ZTl = torch.zeros(self.kp, self.kn, **i16), torch.zeros(self.kp, self.kn, **i16)
+            # The backward product W . Z reads the SAME row-major images as the Gram (vgan_mmd_backward_bf3_rm: B fragments by
+            # transposed LDS reads), so the operand preparation writes no transposed copy of Z (6.6 MB of scattered 16-byte stores
+            # per step at c3).  VGAN_BWD_OPERAND=transposed keeps the round-1 form (ZTh / ZTl) for measurement.
+            self.rm_backward = os.environ.get("VGAN_BWD_OPERAND", "rowmajor") != "transposed"
+            if self.rm_backward:
+                self.ZTh = self.ZTl = None
+            else:
+                self.ZTh, self.ZTl = torch.zeros(self.kp, self.kn, **i16), torch.zeros(self.kp, self.kn, **i16)
             self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
         self.fused_prepare = (self.bf3 and ops.bf3_fusable(n, d, self.logits.stride(0), data.stride(0), dp) and
                               os.environ.get("VGAN_FUSED_PREPARE", "1") == "1")
@@ -232,14 +239,16 @@ class NoKLStepEngine:
         if self.bf3 and nl % 128 == 0 and want in ("auto", "128"):
             if want == "128" or len(ops.build_tiles(n, 1, rank, world, device=self.dev, tile=128)) >= 512:
                 self.gram_tile = 128
-        # Comm/compute overlap of the data-parallel step: the gradient all-reduce runs on a side stream while the main stream
-        # does the only work of the NEXT step that needs no updated parameter -- the X half of its operand (gather, centre,
-        # split) and the X-X tiles of its Gram, which feed nothing but the reported loss.  The table is then laid out as
-        # [XY and YY tiles | XX tiles]: the step's Gram launch covers the first part, the overlapped launch the second, and
-        # the step tail folds both (one table, one partial buffer).
-        self.overlap = self.exchange if overlap_exchange is None else (bool(overlap_exchange) and self.exchange)
-        # (overlap_exchange="serial": the overlapped schedule's launches on ONE stream -- a measurement aid that separates the
-        # price of the extra launches from the price of the cross-stream edges)
+        # Overlap of the step's tail with the only work of the NEXT step that needs no updated parameter: the X half of its
+        # operand (gather, centre, split) and the X-X tiles of its Gram, which feed nothing but the reported loss.  They run on
+        # a side stream that forks right after the MMD backward launch (whose riding step tail has advanced the batch cursor)
+        # and joins at the end of the step -- concurrent with the mask backward, the M_4 contraction, the gradient all-reduce of
+        # a data-parallel run, the chain backward and the optimiser, all of which are small launches that leave most CUs
+        # idle.  The table is laid out as [XY and YY tiles | XX tiles]: the step's Gram launch covers the first part (392
+        # instead of 528 tiles at n = 1024: no second round on the 512 resident slots), the side launch the second, and the
+        # step tail folds both (one table, one partial buffer).  overlap_exchange=False: the plain one-stream schedule with
+        # the XX tiles inside the Gram launch; "serial": the overlapped schedule's launches on ONE stream (measurement aid).
+        self.overlap = True if overlap_exchange is None else bool(overlap_exchange)
         self._side = torch.cuda.Stream(device=self.dev) if (self.overlap and data.is_cuda and overlap_exchange != "serial") else None
         if self.overlap:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
@@ -288,22 +297,20 @@ class NoKLStepEngine:
             ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], False, **rowsel)
             ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, tx, False, None, 0, px)
 
-    def _all_reduce_overlapped(self, dist, tensor):
-        """all-reduce(SUM) of the generator gradient on the side stream, with the next step's parameter-independent work
-        (`_prefetch_xx`) on the main stream; joined before the first launch that reads the reduced gradient."""
+    def _fork_prefetch(self):
+        """Starts the next step's parameter-independent work (`_prefetch_xx`) on the side stream."""
         if not self.overlap:
-            dist.all_reduce(tensor, group=self.group)
             return
-        if self._side is None:  # CPU provider (tests): same order of operations, no streams
-            dist.all_reduce(tensor, group=self.group)
+        if self._side is None:  # CPU provider (tests) / "serial": same order of operations on one stream
             self._prefetch_xx()
             return
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
+        self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side):
-            dist.all_reduce(tensor, group=self.group)
-        self._prefetch_xx()
-        main.wait_stream(self._side)
+            self._prefetch_xx()
+
+    def _join_prefetch(self):
+        if self.overlap and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def shuffle_epoch(self, epoch):
         """This epoch's shuffled drop_last batches from the device-side counter-based permutation (vgan_shuffle_epoch), keyed
@@ -372,7 +379,7 @@ class NoKLStepEngine:
             if dist:
                 if self.splits > 1:
                     ops.reduce_slabs(self.gslab, self.fp.total, self.splits, self.fp.grad)
-                self._all_reduce_overlapped(dist, self.fp.grad)
+                dist.all_reduce(self.fp.grad, group=self.group)
                 ops.adadelta_step(self.fp.flat, self.fp.grad, self.fp.sq, self.fp.acc, **adadelta)
             elif self.splits > 1:  # no exchange: Adadelta sums the slabs itself
                 ops.adadelta_step(self.fp.flat, self.gslab[0], self.fp.sq, self.fp.acc, nslabs=self.splits, slab_stride=self.fp.total,
@@ -386,7 +393,7 @@ class NoKLStepEngine:
         # slab-summing staging loads in the consumers, were both measured slower)
         ops.linear_backward_params(self.dlogits_pad, self.z_own, self.M[4][:self.dp], None)  # pad columns are zero: rows d.. of M_4 too
         if dist:
-            self._all_reduce_overlapped(dist, self.M[4])
+            dist.all_reduce(self.M[4], group=self.group)  # (the side stream's prefetch may still be running beside it)
         # M_{k-1} = Wt_k^T M_k, i.e. M_3 = Wt_4^T M_4, M_2 = B_3^T M_4, M_1 = B_2^T M_4 (At_0 = I: Gt_1 IS M_1), and
         # [dW_k | db_k] = Gt_k = M_k . At_{k-1}^T: two dependency levels
         M, Gt, At = self.M, self.Gt, self.At
@@ -463,14 +470,19 @@ class NoKLStepEngine:
                                          self.step_counter)
         fin = self._fin
         if bf3:
-            ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
-                                 gstride, fin, mul_shift=self.center, tile=self.bwd_tile)
-            ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
+            if self.rm_backward:
+                ops.mmd_backward_bf3_rm(self.Wh, self.Wl, self.Zh, self.Zl, 2 * n, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU,
+                                        self.bsplits, gstride, fin, mul_shift=self.center, tile=self.bwd_tile)
+            else:
+                ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
+                                     gstride, fin, mul_shift=self.center, tile=self.bwd_tile)
         else:
             ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride, fin,
                              mul_shift=self.center)
-            ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
+        self._fork_prefetch()  # the batch cursor has advanced (step tail in the launch above); nothing below touches the X half
+        ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         self._generator_backward_update(dist)
+        self._join_prefetch()
 
     def _step_body(self):
         self._forward()
