@@ -316,11 +316,14 @@ int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count, const vga
  * ZTh, ZTl [kp, kn] of Z (pad regions are not touched: pre-zeroed by the caller).  Shape contract: d % 4 == 0,
  * d <= 1024, n % 8 == 0, leading dimensions % 4 == 0, 16-byte aligned bases; otherwise use the two calls
  * (with norm_split = 1).  center as in vgan_mask_project_forward; sq holds the norms of the split values.
- * ZTh / ZTl may both be NULL (callers of vgan_mmd_backward_bf3_rm need no transposed images). */
+ * ZTh / ZTl may both be NULL (callers of vgan_mmd_backward_bf3_rm need no transposed images).
+ * write_x == 0 (needs ZTh == NULL): the X half of Z, sq, Zh, Zl is left alone -- vgan_gather_rows_split has already produced
+ * it for this batch (the step engine runs that ahead of the step, on a side stream). */
 int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                   const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z,
                                   int ldz, float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,
-                                  uint16_t* ZTl, int kn, int n, int d, const float* center, vgan_stream_t stream);
+                                  uint16_t* ZTl, int kn, int n, int d, const float* center, int write_x,
+                                  vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

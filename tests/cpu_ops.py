@@ -112,11 +112,17 @@ class CpuOps:
         sqy.copy_(torch.as_tensor((Y.astype(np.float64) ** 2).sum(1)))
 
     def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
-                                 center=None):
+                                 center=None, write_x=True):
         n, d = logits.shape
-        self.mask_project_forward(logits, data, rows, S, None, Z[:n], Z[n:], sq[:n], sq[n:], row_cursor, row_batches, row_stride,
-                                  center=center, norm_split=True)
-        self.mmd_bf3_prepare(Z, 2 * n, d, Zh, Zl, ZTh, ZTl)
+        if write_x:
+            self.mask_project_forward(logits, data, rows, S, None, Z[:n], Z[n:], sq[:n], sq[n:], row_cursor, row_batches, row_stride,
+                                      center=center, norm_split=True)
+            self.mmd_bf3_prepare(Z, 2 * n, d, Zh, Zl, ZTh, ZTl)
+        else:  # the X half is already in place (gather_rows_split ran ahead): only the Y half is produced
+            assert ZTh is None
+            self.mask_project_forward(logits, data, rows, S, None, None, Z[n:], None, sq[n:], row_cursor, row_batches, row_stride,
+                                      center=center, norm_split=True)
+            self.mmd_bf3_prepare(Z[n:], n, d, Zh[n:], Zl[n:])
 
     @staticmethod
     def bf3_fusable(n, d, *lds):

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                                                                  int ldz, float* __restrict__ sq, unsigned short* __restrict__ Zh,
                                                                  unsigned short* __restrict__ Zl, int kp, unsigned short* __restrict__ ZTh,
                                                                  unsigned short* __restrict__ ZTl, int kn, int n, int d,
-                                                                 const float* __restrict__ center) {
+                                                                 const float* __restrict__ center, int write_x) {
     constexpr int R = 8;  // rows per workgroup = waves per workgroup (512 threads; 4 rows in 256 threads measured the same: 11.7 us)
     extern __shared__ __attribute__((aligned(16))) unsigned short tile[];  // [4 images: Xh, Xl, Yh, Yl][R][ldt]
     const int ldt = 4 * (d >> 2) + 8;                     // bf16 elements per tile row (8-byte stores stay aligned)
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                     const float4 y4 = make_float4(project_centred(u4.x, xv[t].x, cv[t].x), project_centred(u4.y, xv[t].y, cv[t].y), project_centred(u4.z, xv[t].z, cv[t].z),
                                               project_centred(u4.w, xv[t].w, cv[t].w));
                     reinterpret_cast<float4*>(S + (long)i * d)[q] = s4;
-                    reinterpret_cast<float4*>(Z + (long)i * ldz)[q] = x4c;
+                    if (write_x) reinterpret_cast<float4*>(Z + (long)i * ldz)[q] = x4c;
                     reinterpret_cast<float4*>(Z + (long)(n + i) * ldz)[q] = y4;
                     const float xs[4] = {x4c.x, x4c.y, x4c.z, x4c.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
                     unsigned short h[2][4], l[2][4];
@@ -239,8 +239,10 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                         const uint2 ph = make_uint2((unsigned)h[im][0] | ((unsigned)h[im][1] << 16), (unsigned)h[im][2] | ((unsigned)h[im][3] << 16));
                         const uint2 pl = make_uint2((unsigned)l[im][0] | ((unsigned)l[im][1] << 16), (unsigned)l[im][2] | ((unsigned)l[im][3] << 16));
                         const long grow = (long)(im * n + i) * kp + 4 * q;
-                        *reinterpret_cast<uint2*>(Zh + grow) = ph;
-                        *reinterpret_cast<uint2*>(Zl + grow) = pl;
+                        if (im == 1 || write_x) {  // (the X half may already be in place: vgan_gather_rows_split ran ahead)
+                            *reinterpret_cast<uint2*>(Zh + grow) = ph;
+                            *reinterpret_cast<uint2*>(Zl + grow) = pl;
+                        }
                         if (ZTh != nullptr) {
                             *reinterpret_cast<uint2*>(tile + ((2 * im) * R + lr) * ldt + 4 * q) = ph;
                             *reinterpret_cast<uint2*>(tile + ((2 * im + 1) * R + lr) * ldt + 4 * q) = pl;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
             nx = wave_sum(nx);
             ny = wave_sum(ny);
             if (lane == 0) {
-                sq[i] = nx;
+                if (write_x) sq[i] = nx;
                 sq[n + i] = ny;
             }
         } else if (ZTh != nullptr) {  // rows past the batch: their tile rows are read by the transposed store below (full 16-byte pieces)
@@ -497,10 +499,11 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
 extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                              const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z, int ldz,
                                              float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh, uint16_t* ZTl, int kn,
-                                             int n, int d, const float* center, vgan_stream_t stream) {
+                                             int n, int d, const float* center, int write_x, vgan_stream_t stream) {
     VGAN_CHECK_ARG(logits && data && S && Z && sq && Zh && Zl && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
     VGAN_CHECK_ARG((ZTh == nullptr) == (ZTl == nullptr));
     VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && kp >= d && kp % 64 == 0 && (ZTh == nullptr || (kn >= 2 * n && kn % 64 == 0)));
+    VGAN_CHECK_ARG(write_x || ZTh == nullptr);  // the transposed images are always written whole
     // shape contract of the fused path (callers fall back to vgan_mask_project_forward + vgan_mmd_bf3_prepare otherwise)
     VGAN_CHECK_ARG(d % 4 == 0 && d <= 1024 && n % 8 == 0 && ldl % 4 == 0 && ldd % 4 == 0 && ldz % 4 == 0);
     VGAN_CHECK_ARG(aligned16(logits) && aligned16(data) && aligned16(S) && aligned16(Z) && aligned16(Zh) && aligned16(Zl) &&
@@ -517,7 +520,7 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_bf3_kernel<NT>),                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                      \
         hipLaunchKernelGGL(mask_forward_bf3_kernel<NT>, grid, block, shmem, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, Zh, Zl, kp, \
-                           ZTh, ZTl, kn, n, d, center);                                                                             \
+                           ZTh, ZTl, kn, n, d, center, write_x);                                                                    \
     } while (0)
     if (nt == 1) VGAN_LAUNCH_FWD3(1); else if (nt == 2) VGAN_LAUNCH_FWD3(2); else if (nt == 3) VGAN_LAUNCH_FWD3(3); else VGAN_LAUNCH_FWD3(4);
 #undef VGAN_LAUNCH_FWD3

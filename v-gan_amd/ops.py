@@ -117,7 +117,7 @@ class HipOps:
                                                       n, d, _ptr(center), int(bool(norm_split)), self._stream()), "vgan_mask_project_forward")
 
     def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
-                                 center=None):
+                                 center=None, write_x=True):
         """mask_project_forward + mmd_bf3_prepare in one launch (shape contract in include/vgan_hip.h; see bf3_fusable)."""
         _mat(logits, "logits"), _mat(data, "data"), _mat(Z, "Z")
         n, d = logits.shape
@@ -125,7 +125,8 @@ class HipOps:
                                                           _ptr(row_cursor), int(row_batches), int(row_stride), _ptr(S), _ptr(Z), Z.stride(0),
                                                           _ptr(sq), _ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(ZTh), _ptr(ZTl),
                                                           ZTh.stride(0) if ZTh is not None else 0,
-                                                          n, d, _ptr(center), self._stream()), "vgan_mask_project_forward_bf3")
+                                                          n, d, _ptr(center), int(bool(write_x)), self._stream()),
+                   "vgan_mask_project_forward_bf3")
 
     @staticmethod
     def bf3_fusable(n, d, *lds):

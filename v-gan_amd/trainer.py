@@ -215,6 +215,7 @@ class NoKLStepEngine:
         self.dlogits = self.dlogits_pad[:, :d]
         # MMD arithmetic: "fp32" (fp32 MFMA, default) or "bf16x3" (split-bf16 operands on the bf16 MFMA, see
         # csrc/mmd_bf16.hip: ~3e-7 relative on a Gram entry at K = 784, a third of the time)
+        self.rm_backward = True
         if self.precision == "bf16x3":
             i16 = dict(dtype=torch.int16, device=self.dev)
             self.kp, self.kn = (d + 63) // 64 * 64, (2 * n + 63) // 64 * 64
@@ -248,8 +249,17 @@ class NoKLStepEngine:
         # instead of 528 tiles at n = 1024: no second round on the 512 resident slots), the side launch the second, and the
         # step tail folds both (one table, one partial buffer).  overlap_exchange=False: the plain one-stream schedule with
         # the XX tiles inside the Gram launch; "serial": the overlapped schedule's launches on ONE stream (measurement aid).
-        self.overlap = True if overlap_exchange is None else bool(overlap_exchange)
+        if overlap_exchange is None and os.environ.get("VGAN_OVERLAP") is not None:  # measurement knob: 1 | 0 | serial
+            overlap_exchange = {"1": True, "0": False}.get(os.environ["VGAN_OVERLAP"], os.environ["VGAN_OVERLAP"])
+        # MEASURED (MI355X, c3, same box, profiles/r02_overlap_schedules.txt): the side-stream schedule LOSES on this stack --
+        # 6 843-6 972 steps/s against 8 259-8 529 plain on one GPU; emulated 1/8 shard 120 us against 87 (plain) and 105 (same
+        # launches on one stream).  The Gram does drop from 24.2 to 14.2 us without its 136 X-X tiles, but two kernels running
+        # side by side inside the graph slow each other (M_4 product 8.5 -> 13.0 us, mask backward 5.1 -> 6.9) and the fork /
+        # join is not free.  The default is therefore the plain schedule; the option stays for stacks where streams are cheap.
+        self.overlap = False if overlap_exchange is None else bool(overlap_exchange)
         self._side = torch.cuda.Stream(device=self.dev) if (self.overlap and data.is_cuda and overlap_exchange != "serial") else None
+        # with the X half of the operand produced ahead of the step, the mask / projection launch writes the Y half only
+        self.x_ahead = self.overlap and (not self.bf3 or self.rm_backward)
         if self.overlap:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
         else:
@@ -283,18 +293,27 @@ class NoKLStepEngine:
 
     def _prefetch_xx(self):
         """X half of the operand of the batch the device-side cursor points at, and its X-X tiles (sums only)."""
-        ops, n, nl, lo = self.ops, self.n, self.nl, self.lo
-        rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
-        ntx = self.tiles.shape[0] - self.n_main
+        self._prefetch_x_operand()
+        self._xx_tiles()
         self._xx_primed = True
+
+    def _prefetch_x_operand(self):
+        ops, n = self.ops, self.n
+        rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
+        if self.bf3:
+            ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], True, self.Zh[:n], self.Zl[:n], **rowsel)
+        else:
+            ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], False, **rowsel)
+
+    def _xx_tiles(self):
+        ops, n = self.ops, self.n
+        ntx = self.tiles.shape[0] - self.n_main
         if ntx == 0:
             return
         tx, px = self.tiles[self.n_main:], self.partial[self.n_main:self.n_main + ntx]
         if self.bf3:
-            ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], True, self.Zh[:n], self.Zl[:n], **rowsel)
             ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, tx, None, None, 0, px, tile=self.gram_tile)
         else:
-            ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], False, **rowsel)
             ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, tx, False, None, 0, px)
 
     def _fork_prefetch(self):
@@ -433,10 +452,14 @@ class NoKLStepEngine:
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
         if self.fused_prepare:  # mask/projection and the bf16x3 operand split in one launch
             ops.mask_project_forward_bf3(self.logits, self.data, self.perm, self.S, self.Z, self.sqn, self.Zh, self.Zl, self.ZTh, self.ZTl,
-                                         center=self.center, **rowsel)
+                                         center=self.center, write_x=not self.x_ahead, **rowsel)
             return
-        ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n], self.sqn[n:],
-                                 row_offset=0, center=self.center, norm_split=self.bf3, **rowsel)
+        if self.x_ahead:  # the X half of Z / sq (and of the split images) is already in place
+            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, None, self.Z[n:], None, self.sqn[n:],
+                                     row_offset=0, center=self.center, norm_split=self.bf3, **rowsel)
+        else:
+            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n], self.sqn[n:],
+                                     row_offset=0, center=self.center, norm_split=self.bf3, **rowsel)
 
     def _calibrate(self):
         """First-call bandwidth (src/models/Mmd_loss_constrained.py:16-20): sum(L) / (N^2 - N)."""
@@ -454,7 +477,10 @@ class NoKLStepEngine:
         gstride = nl * self.dp
         bf3 = self.precision == "bf16x3"
         if bf3 and not self.fused_prepare:
-            ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
+            if self.x_ahead:
+                ops.mmd_bf3_prepare(self.Z[n:], n, d, self.Zh[n:], self.Zl[n:])
+            else:
+                ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
         if bf3:
             ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles[:self.n_main], self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
                              self.colpart, True, tile=self.gram_tile)
@@ -491,10 +517,13 @@ class NoKLStepEngine:
     def step(self):
         """Runs one training step asynchronously.  The first step also calibrates the bandwidth."""
         if not self.has_bw:
+            if self.overlap:  # no step ran before this one: the X half of its operand is produced here ...
+                self._prefetch_x_operand()
             self._forward()
             self._calibrate()
-            if self.overlap:  # no step ran before this one: its X-X sums are computed here, with the fresh bandwidth
-                self._prefetch_xx()
+            if self.overlap:  # ... and its X-X sums here, with the fresh bandwidth
+                self._xx_tiles()
+                self._xx_primed = True
             self._loss_backward_update()
         elif self.use_graph and self.steps_done > 0:
             if self.graph is None:
