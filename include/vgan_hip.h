@@ -318,12 +318,27 @@ int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count, const vga
  * (with norm_split = 1).  center as in vgan_mask_project_forward; sq holds the norms of the split values.
  * ZTh / ZTl may both be NULL (callers of vgan_mmd_backward_bf3_rm need no transposed images).
  * write_x == 0 (needs ZTh == NULL): the X half of Z, sq, Zh, Zl is left alone -- vgan_gather_rows_split has already produced
- * it for this batch (the step engine runs that ahead of the step, on a side stream). */
+ * it for this batch.
+ * xx (may be NULL; needs ZTh == NULL): the X-X tiles of the Gram ride in this launch as surplus workgroups.  They only
+ * feed the block sum of the reported loss and depend on nothing the step computes: their operand is this batch's rows of
+ * the data set, gathered by the same index table from split images prepared once per fit -- Dh, Dl [data rows, ldd] and dsq
+ * (vgan_gather_rows_split over the whole data set with norm_split = 1).  tiles / ntiles: the X-X part of the tile table
+ * (vgan_mmd_build_tiles, flags slot 0); partial: where their sums go (4 floats per tile, the layout vgan_mmd_finalize folds);
+ * bw: the frozen bandwidth.  The Gram launch then covers the XY and YY tiles only. */
+typedef struct vgan_xx_job {
+    const uint16_t* Dh;
+    const uint16_t* Dl;
+    const float* dsq;
+    const int32_t* tiles;
+    const float* bw;
+    float* partial;
+    int32_t ldd, ntiles;
+} vgan_xx_job;
 int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                   const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z,
                                   int ldz, float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,
                                   uint16_t* ZTl, int kn, int n, int d, const float* center, int write_x,
-                                  vgan_stream_t stream);
+                                  const vgan_xx_job* xx, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

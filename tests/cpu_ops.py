@@ -111,9 +111,20 @@ class CpuOps:
             sqx.copy_(torch.as_tensor((X.astype(np.float64) ** 2).sum(1)))
         sqy.copy_(torch.as_tensor((Y.astype(np.float64) ** 2).sum(1)))
 
+    def xx_job(self, Dh, Dl, dsq, tiles, bw, partial):
+        return dict(Dh=Dh, Dl=Dl, dsq=dsq, tiles=tiles, bw=bw, partial=partial)
+
     def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
-                                 center=None, write_x=True):
+                                 center=None, write_x=True, xx=None):
         n, d = logits.shape
+        if xx is not None:  # the X-X tiles of this batch from the data set's split images, gathered by the batch indices
+            idx = torch.as_tensor(self._rows(rows, row_cursor, row_batches, row_stride, 0, n))
+            Xh = torch.zeros(2 * n, xx["Dh"].shape[1], dtype=torch.int16)
+            Xl = torch.zeros_like(Xh)
+            Xh[:n], Xl[:n] = xx["Dh"][idx], xx["Dl"][idx]
+            sqx = torch.zeros(2 * n)
+            sqx[:n] = xx["dsq"][idx]
+            self.mmd_gram_bf3(Xh, Xl, sqx, n, xx["bw"], xx["tiles"], None, None, 0, xx["partial"])
         if write_x:
             self.mask_project_forward(logits, data, rows, S, None, Z[:n], Z[n:], sq[:n], sq[n:], row_cursor, row_batches, row_stride,
                                       center=center, norm_split=True)

@@ -91,6 +91,29 @@ def test_engine_fused_update_path_equals_separate_optimiser_launch():
         assert torch.equal(a, b)
 
 
+def test_xx_tiles_riding_in_the_forward_launch_equal_the_gram_launch(monkeypatch):
+    """bf16x3 mode, fused forward: the X-X tiles computed as a job of the mask / projection launch -- from the data set's split
+    images through the batch index table (csrc/mmd_xx.hpp) -- give the same losses and parameters as the same tiles inside the
+    Gram launch, across an epoch boundary and a dropped remainder (CPU provider)."""
+    g = load_golden("f3_traj_c1.npz")
+    res = {}
+    for ride in ("1", "0"):
+        monkeypatch.setenv("VGAN_XX_RIDE", ride)
+        eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["data"], 128, 10, mmd_precision="bf16x3")
+        assert eng.xx_ride == (ride == "1") and eng.fused_prepare
+        losses = []
+        for t in range(14):
+            if t % 10 == 0:
+                eng.set_epoch_batches(torch.as_tensor(g["idx"][t:t + 10].astype(np.int64)))
+            eng.set_noise(torch.as_tensor(g["noise"][t]))
+            eng.step()
+            losses.append(float(eng.loss))
+        res[ride] = (np.array(losses), eng.fp.flat.clone())
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(res["1"][0], g["losses"][:14], rtol=0, atol=1e-4)
+    assert torch.equal(res["1"][1], res["0"][1])  # the X-X sums feed the reported loss only, never a gradient
+
+
 def test_engine_bf16x3_precision_mode_vs_reference_fixture():
     """Split-bf16 MMD mode (emulated on the CPU stand-in with torch.bfloat16 roundings): the step still meets the loss bar."""
     g = load_golden("f2_step_c2.npz")

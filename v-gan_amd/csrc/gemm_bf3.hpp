@@ -49,12 +49,16 @@ struct GemmBF3 {
         u32x4 v[4][NR];  // [part][r]
         const char* src[4][NR];
         int lofs[NR];
+        // amap / bmap (optional): operand row g is stored at image row map[g] (a batch gathered by index from a resident
+        // image: one dependent lookup per staged row, at tile start only)
         __device__ __forceinline__ void init(const unsigned short* Ah, const unsigned short* Al, long lda, int m0, int M,
-                                             const unsigned short* Bh, const unsigned short* Bl, long ldb, int n0, int N, int tid) {
+                                             const unsigned short* Bh, const unsigned short* Bl, long ldb, int n0, int N, int tid,
+                                             const int* amap = nullptr, const int* bmap = nullptr) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int f = tid + kBlock * r, row = f / QPR, q = f % QPR;
-                const long ra = (long)min(m0 + row, M - 1) * lda + 8 * q, rb = (long)min(n0 + row, N - 1) * ldb + 8 * q;
+                const int ga = min(m0 + row, M - 1), gb = min(n0 + row, N - 1);
+                const long ra = (long)(amap ? amap[ga] : ga) * lda + 8 * q, rb = (long)(bmap ? bmap[gb] : gb) * ldb + 8 * q;
                 src[0][r] = reinterpret_cast<const char*>(Ah + ra);
                 src[1][r] = reinterpret_cast<const char*>(Al + ra);
                 src[2][r] = reinterpret_cast<const char*>(Bh + rb);
@@ -89,18 +93,21 @@ struct GemmBF3 {
     };
 
     // acc (+)= A[m0.., :] . B[n0.., :]^T over K (multiple of 64).  SIDE_A: rs_lds[64] = sum_k A[m0 + m, k].
+    // (thread ids are taken modulo 256: a 512-thread workgroup may run TWO tiles side by side, waves 0-3 and 4-7 each on
+    //  their own LDS region -- both halves execute the same number of barriers, K being the same)
     template <bool SIDE_A>
     __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
                                                const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K,
-                                               char* lds_generic, float* rs_generic, f32x16& acc) {
+                                               char* lds_generic, float* rs_generic, f32x16& acc, const int* amap = nullptr,
+                                               const int* bmap = nullptr) {
         typedef char __attribute__((address_space(3))) lds_c;
         lds_c* lds = (lds_c*)lds_generic;
         lds_f* rs_lds = (lds_f*)rs_generic;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x & (kBlock - 1), lane = tid & 63, wave = tid >> 6;
         const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
         const int fi = lane & 31, fh = lane >> 5;
         Stage st;
-        st.init(Ah, Al, lda, m0, M, Bh, Bl, ldb, n0, N, tid);
+        st.init(Ah, Al, lda, m0, M, Bh, Bl, ldb, n0, N, tid, amap, bmap);
         float rsum[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) rsum[r] = 0.f;
@@ -176,11 +183,11 @@ struct GemmBF3 {
         }
     }
     __device__ static __forceinline__ int sub_row(int r) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
         return (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     }
     __device__ static __forceinline__ int sub_col() {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
         return (wave & 1) * 32 + (lane & 31);
     }
 

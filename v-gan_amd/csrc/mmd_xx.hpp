@@ -1,0 +1,67 @@
+// X-X tiles of the Gram (block sums only: they feed the reported loss, never a gradient) as a job that rides in ANOTHER launch.
+//
+// They depend on nothing the step produces: their operand is the batch's rows of the data set, whose centred split images
+// (Dh, Dl) and norms (dsq) are prepared ONCE per fit; the batch is gathered by index (the epoch's table + the device-side step
+// counter) while the tiles are staged.  Taken out of the Gram launch they leave it with 392 instead of 528 tiles at n = 1024 --
+// one round on the 512 resident slots instead of two: 24.2 -> 14.2 us -- and inside the mask / projection launch (HBM-bound,
+// half of the CUs idle) they are nearly free.  Running them on a side stream instead was measured slower
+// (profiles/r02_overlap_schedules.txt).
+#pragma once
+#include "gemm_bf3.hpp"
+#include "mmd_common.hpp"
+
+namespace vgan {
+
+struct XXJob {
+    const unsigned short *Dh, *Dl;   // [rows of the data set, ldd] split images of (data - centre); pad columns zero
+    const float* dsq;                // their squared norms (of the split values)
+    const int* rows;                 // epoch table of batch indices, or nullptr: batch row i = data row i
+    const unsigned long long* cursor;
+    const TileDesc* tiles;           // the X-X tiles (r0, c0 < n)
+    const float* bw;
+    float* partial;                  // [ntiles][4]
+    int ldd, row_batches, row_stride, ntiles, n;
+};
+
+// One 512-thread workgroup = two tiles (waves 0-3 and 4-7), `pair` = index of the pair.  lds: 2 x GemmBF3<64>::kLdsBytes.
+__device__ __forceinline__ void xx_tile_pair_body(const XXJob& job, int pair, char* lds, float* red /* [8] */) {
+    using G = GemmBF3<64>;
+    const int half = threadIdx.x >> 8, lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int t = 2 * pair + half;
+    const bool valid = t < job.ntiles;  // an odd tile count leaves one half idle: it runs a clamped tile for the barriers' sake
+    const TileDesc td = job.tiles[min(t, job.ntiles - 1)];
+    const int* map = job.rows;
+    if (map != nullptr) map += (long)(job.cursor ? (long)(job.cursor[0] % (unsigned long long)job.row_batches) : 0l) * job.row_stride;
+    auto row_of = [&](int g) { return map ? map[g] : g; };
+    const int j = td.c0 + G::sub_col();
+    const bool jok = j < td.clim;
+    const float sj = job.dsq[row_of(min(j, td.clim - 1))];
+    const float bw = job.bw[0];
+    float si_pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) si_pre[r] = job.dsq[row_of(min(td.r0 + G::sub_row(r), td.rlim - 1))];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    G::template run<false>(job.Dh, job.Dl, job.ldd, job.Dh, job.Dl, job.ldd, td.r0, td.c0, td.rlim, td.clim, job.ldd,
+                           lds + half * G::kLdsBytes, nullptr, acc, map, map);
+    const float c2 = -1.4426950408889634f / (4.f * bw);
+    float ksum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = td.r0 + G::sub_row(r);
+        const bool ok = jok && (i < td.rlim);
+        const float L = fmaxf(si_pre[r] + sj - 2.f * acc[r], 0.f);
+        const float tt = __builtin_amdgcn_exp2f(L * c2);
+        const float t2 = tt * tt, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+        ksum += ok ? ((tt + t2) + (t4 + t8)) + t16 : 0.f;
+    }
+    ksum = wave_sum(ksum);
+    if (lane == 0) red[half * 4 + wave] = ksum;
+    __syncthreads();
+    if ((threadIdx.x & 255) == 0 && valid)
+        reinterpret_cast<float4*>(job.partial)[t] =
+            make_float4((red[half * 4] + red[half * 4 + 1]) + (red[half * 4 + 2] + red[half * 4 + 3]), 0.f, 0.f, 0.f);
+}
+
+}  // namespace vgan

@@ -6,6 +6,7 @@
 //
 // All are HBM/L2-streaming kernels: one 64-lane wave per row, coalesced 256-byte wave accesses,
 // reductions by wave shuffles only (no LDS).
+#include "mmd_xx.hpp"
 #include "vgan_common.hpp"
 
 namespace vgan {
@@ -162,14 +163,24 @@ __global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* _
 // the split images of both the X row and the Y = U*X row: row-major (Zh, Zl) straight from registers, transposed
 // (ZTh, ZTl: [feature][row]) through an LDS tile, so that 8 rows leave as one 16-byte store per feature and image.  This
 // removes the separate preparation launch (~6 us of a ~120 us step at d = 784) and its 13 MB re-read of Z.
-template <int NT>
+// XX: workgroups past the row groups run the X-X tiles of the NEXT Gram launch (mmd_xx.hpp), two tiles each.
+template <int NT, bool XX>
 __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
                                                                  int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ Z,
                                                                  int ldz, float* __restrict__ sq, unsigned short* __restrict__ Zh,
                                                                  unsigned short* __restrict__ Zl, int kp, unsigned short* __restrict__ ZTh,
                                                                  unsigned short* __restrict__ ZTl, int kn, int n, int d,
-                                                                 const float* __restrict__ center, int write_x) {
+                                                                 const float* __restrict__ center, int write_x, int mask_blocks,
+                                                                 XXJob xx) {
     constexpr int R = 8;  // rows per workgroup = waves per workgroup (512 threads; 4 rows in 256 threads measured the same: 11.7 us)
+    if constexpr (XX) {
+        __shared__ __attribute__((aligned(16))) char xx_lds[2 * GemmBF3<64>::kLdsBytes];
+        __shared__ float xx_red[8];
+        if ((int)blockIdx.x >= mask_blocks) {  // block-uniform
+            xx_tile_pair_body(xx, blockIdx.x - mask_blocks, xx_lds, xx_red);
+            return;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned short tile[];  // [4 images: Xh, Xl, Yh, Yl][R][ldt]
     const int ldt = 4 * (d >> 2) + 8;                     // bf16 elements per tile row (8-byte stores stay aligned)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -499,7 +510,8 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
 extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                              const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z, int ldz,
                                              float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh, uint16_t* ZTl, int kn,
-                                             int n, int d, const float* center, int write_x, vgan_stream_t stream) {
+                                             int n, int d, const float* center, int write_x, const vgan_xx_job* xxjob,
+                                             vgan_stream_t stream) {
     VGAN_CHECK_ARG(logits && data && S && Z && sq && Zh && Zl && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
     VGAN_CHECK_ARG((ZTh == nullptr) == (ZTl == nullptr));
     VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && kp >= d && kp % 64 == 0 && (ZTh == nullptr || (kn >= 2 * n && kn % 64 == 0)));
@@ -509,18 +521,34 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
     VGAN_CHECK_ARG(aligned16(logits) && aligned16(data) && aligned16(S) && aligned16(Z) && aligned16(Zh) && aligned16(Zl) &&
                    (ZTh == nullptr || (aligned16(ZTh) && aligned16(ZTl))) && (center == nullptr || aligned16(center)));
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, 0};
-    const dim3 grid(8 * ((n / 8 + 7) / 8)), block(512);
+    const int mask_blocks = 8 * ((n / 8 + 7) / 8);
+    XXJob xx{};
+    int xx_blocks = 0;
+    if (xxjob != nullptr) {
+        const vgan_xx_job& j = *xxjob;
+        VGAN_CHECK_ARG(ZTh == nullptr && j.Dh && j.Dl && j.dsq && j.tiles && j.bw && j.partial && j.ntiles > 0 && j.ldd >= d && j.ldd % 64 == 0);
+        VGAN_CHECK_ARG(aligned16(j.Dh) && aligned16(j.Dl) && (reinterpret_cast<uintptr_t>(j.partial) & 15) == 0);
+        xx = XXJob{j.Dh, j.Dl, j.dsq, rows, reinterpret_cast<const unsigned long long*>(row_cursor), reinterpret_cast<const TileDesc*>(j.tiles),
+                   j.bw, j.partial, j.ldd, row_batches, row_stride, j.ntiles, n};
+        xx_blocks = (j.ntiles + 1) / 2;
+    }
+    const dim3 grid(mask_blocks + xx_blocks), block(512);
     const size_t shmem = ZTh != nullptr ? (size_t)4 * 8 * (d + 8) * sizeof(unsigned short) : 0;
     hipStream_t st = (hipStream_t)stream;
     const int nt = (d / 4 + 63) / 64;
     // (dynamic LDS above 64 KB -- d close to 1024 -- needs the opt-in; setting it is idempotent and cheap)
 #define VGAN_LAUNCH_FWD3(NT)                                                                                                        \
     do {                                                                                                                            \
-        if (shmem > 64 * 1024)                                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_bf3_kernel<NT>),                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                      \
-        hipLaunchKernelGGL(mask_forward_bf3_kernel<NT>, grid, block, shmem, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, Zh, Zl, kp, \
-                           ZTh, ZTl, kn, n, d, center, write_x);                                                                    \
+        if (xx_blocks > 0) {                                                                                                        \
+            hipLaunchKernelGGL((mask_forward_bf3_kernel<NT, true>), grid, block, 0, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, Zh, \
+                               Zl, kp, ZTh, ZTl, kn, n, d, center, write_x, mask_blocks, xx);                                        \
+        } else {                                                                                                                    \
+            if (shmem > 64 * 1024)                                                                                                  \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_bf3_kernel<NT, false>),                         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
+            hipLaunchKernelGGL((mask_forward_bf3_kernel<NT, false>), grid, block, shmem, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, \
+                               Zh, Zl, kp, ZTh, ZTl, kn, n, d, center, write_x, mask_blocks, xx);                                    \
+        }                                                                                                                           \
     } while (0)
     if (nt == 1) VGAN_LAUNCH_FWD3(1); else if (nt == 2) VGAN_LAUNCH_FWD3(2); else if (nt == 3) VGAN_LAUNCH_FWD3(3); else VGAN_LAUNCH_FWD3(4);
 #undef VGAN_LAUNCH_FWD3

@@ -25,6 +25,12 @@ class GemmProblem(ctypes.Structure):
                 ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
+class XXJob(ctypes.Structure):
+    """struct vgan_xx_job (include/vgan_hip.h): the X-X Gram tiles riding in the mask / projection launch."""
+    _fields_ = [("Dh", _p), ("Dl", _p), ("dsq", _p), ("tiles", _p), ("bw", _p), ("partial", _p), ("ldd", ctypes.c_int32),
+                ("ntiles", ctypes.c_int32)]
+
+
 class AdadeltaLayer(ctypes.Structure):
     """struct vgan_adadelta_layer (include/vgan_hip.h)."""
     _fields_ = [("w_packed", _p), ("off_w", _i64), ("off_b", _i64), ("ldp", ctypes.c_int32), ("out", ctypes.c_int32),
@@ -83,7 +89,7 @@ SIGNATURES = {
     "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _u64, _p, _p]),
     "vgan_gemm_grouped": (_i, [_p, _i, _p]),
     "vgan_gemm_grouped_ex": (_i, [_p, _i, _p, _p]),
-    "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p]),
+    "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
     "vgan_mse_grad": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
     "vgan_sum_f64": (_i, [_p, _i, ctypes.c_double, _p, _i, _p]),
     "vgan_rbf_kernel_matrix": (_i, [_p, _i, _i, _i, _p, _f, _p, _i, _p]),

@@ -116,8 +116,15 @@ class HipOps:
                                                       _ptr(row_cursor), int(row_batches), int(row_stride), int(row_offset), _ptr(S), _ptr(U), _ptr(Zx), _ptr(Zy), Zy.stride(0), _ptr(sqx), _ptr(sqy),
                                                       n, d, _ptr(center), int(bool(norm_split)), self._stream()), "vgan_mask_project_forward")
 
+    def xx_job(self, Dh, Dl, dsq, tiles, bw, partial):
+        """The X-X Gram tiles as a job for mask_project_forward_bf3 (`xx=`): Dh, Dl, dsq = split images / norms of the whole
+        (centred) data set, tiles / partial = the X-X part of the tile table and of the partial buffer.  Raw pointers: the
+        tensors must outlive every launch (and graph replay) that uses the job."""
+        assert tiles.is_contiguous() and partial.is_contiguous() and Dh.stride(0) == Dl.stride(0)
+        return _lib.XXJob(_ptr(Dh), _ptr(Dl), _ptr(dsq), _ptr(tiles), _ptr(bw), _ptr(partial), Dh.stride(0), tiles.shape[0])
+
     def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
-                                 center=None, write_x=True):
+                                 center=None, write_x=True, xx=None):
         """mask_project_forward + mmd_bf3_prepare in one launch (shape contract in include/vgan_hip.h; see bf3_fusable)."""
         _mat(logits, "logits"), _mat(data, "data"), _mat(Z, "Z")
         n, d = logits.shape
@@ -125,7 +132,8 @@ class HipOps:
                                                           _ptr(row_cursor), int(row_batches), int(row_stride), _ptr(S), _ptr(Z), Z.stride(0),
                                                           _ptr(sq), _ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(ZTh), _ptr(ZTl),
                                                           ZTh.stride(0) if ZTh is not None else 0,
-                                                          n, d, _ptr(center), int(bool(write_x)), self._stream()),
+                                                          n, d, _ptr(center), int(bool(write_x)),
+                                                          ctypes.byref(xx) if xx is not None else None, self._stream()),
                    "vgan_mask_project_forward_bf3")
 
     @staticmethod

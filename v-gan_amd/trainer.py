@@ -260,14 +260,32 @@ class NoKLStepEngine:
         self._side = torch.cuda.Stream(device=self.dev) if (self.overlap and data.is_cuda and overlap_exchange != "serial") else None
         # with the X half of the operand produced ahead of the step, the mask / projection launch writes the Y half only
         self.x_ahead = self.overlap and (not self.bf3 or self.rm_backward)
-        if self.overlap:
+        # bf16x3 mode, fused forward: the X-X tiles (sums only, independent of everything the step computes) ride in the mask /
+        # projection launch as surplus workgroups, reading the batch's rows through the index table from split images of the
+        # whole data set prepared ONCE here (csrc/mmd_xx.hpp).  The Gram launch keeps the XY and YY tiles: 392 instead of 528 at
+        # n = 1024, one round on the chip's 512 resident slots instead of two (24.2 -> 14.2 us).  Riding needs every workgroup
+        # of the launch resident at once at one per CU (the tile pairs hold 147 KB of LDS): 256 CUs.
+        self.xx_ride = False
+        self._xx = None
+        if (self.fused_prepare and self.gram_tile == 64 and not self.overlap and self.rm_backward and
+                os.environ.get("VGAN_XX_RIDE", "1") == "1"):
+            split, n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=64, split_xx=True)
+            xx_pairs = (split.shape[0] - n_main + 1) // 2
+            self.xx_ride = xx_pairs > 0 and 8 * ((n // 8 + 7) // 8) + xx_pairs <= 256
+        if self.xx_ride:
+            i16 = dict(dtype=torch.int16, device=self.dev)
+            rows_total = data.shape[0]
+            self.Dh, self.Dl = torch.zeros(rows_total, self.kp, **i16), torch.zeros(rows_total, self.kp, **i16)
+            self.dsq = torch.zeros(rows_total, **f32)
+            ops.gather_rows_split(data, None, self.center, None, self.dsq, True, self.Dh, self.Dl, n=rows_total)
+        if self.overlap or self.xx_ride:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
         else:
             self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile)
             self.n_main = self.tiles.shape[0]
         # the first-call bandwidth needs sum(L) over ALL pairs: computed by every rank from the full table (no collective)
         # (the calibration launch is the fp32 kernel: 64-wide tiles)
-        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not self.overlap) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
+        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not (self.overlap or self.xx_ride)) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
         self.partial = torch.zeros(max(self.tiles.shape[0], self.tiles_cal.shape[0]), 4, **f32)
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
@@ -451,8 +469,14 @@ class NoKLStepEngine:
         self._generator_forward()
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
         if self.fused_prepare:  # mask/projection and the bf16x3 operand split in one launch
+            xx = None
+            if self.xx_ride and self.has_bw:  # (before the bandwidth exists the first step runs these tiles after its calibration)
+                if self._xx is None:
+                    ntx = self.tiles.shape[0] - self.n_main
+                    self._xx = ops.xx_job(self.Dh, self.Dl, self.dsq, self.tiles[self.n_main:], self.bw, self.partial[self.n_main:self.n_main + ntx])
+                xx = self._xx
             ops.mask_project_forward_bf3(self.logits, self.data, self.perm, self.S, self.Z, self.sqn, self.Zh, self.Zl, self.ZTh, self.ZTl,
-                                         center=self.center, write_x=not self.x_ahead, **rowsel)
+                                         center=self.center, write_x=not self.x_ahead, xx=xx, **rowsel)
             return
         if self.x_ahead:  # the X half of Z / sq (and of the split images) is already in place
             ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, None, self.Z[n:], None, self.sqn[n:],
@@ -521,7 +545,7 @@ class NoKLStepEngine:
                 self._prefetch_x_operand()
             self._forward()
             self._calibrate()
-            if self.overlap:  # ... and its X-X sums here, with the fresh bandwidth
+            if self.overlap or self.xx_ride:  # ... and its X-X sums here, with the fresh bandwidth
                 self._xx_tiles()
                 self._xx_primed = True
             self._loss_backward_update()
