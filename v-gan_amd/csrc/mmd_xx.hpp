@@ -3,9 +3,11 @@
 // They depend on nothing the step produces: their operand is the batch's rows of the data set, whose centred split images
 // (Dh, Dl) and norms (dsq) are prepared ONCE per fit; the batch is gathered by index (the epoch's table + the device-side step
 // counter) while the tiles are staged.  Taken out of the Gram launch they leave it with 392 instead of 528 tiles at n = 1024 --
-// one round on the 512 resident slots instead of two: 24.2 -> 14.2 us -- and inside the mask / projection launch (HBM-bound,
-// half of the CUs idle) they are nearly free.  Running them on a side stream instead was measured slower
-// (profiles/r02_overlap_schedules.txt).
+// one round on the 512 resident slots instead of two: 24.2 -> 17.5 us.  MEASURED on MI355X: inside the mask / projection launch
+// the tiles are NOT free -- their operand, gathered from the data set's images, is HBM-cold (inside the Gram it is the L2-hot
+// image the forward has just written), the K loop turns latency-bound and the carrying launch grows from 9.4 to 18.3 us: a net
+// loss of ~1.5 % of the step rate.  Running them on a side stream was slower still (profiles/r02_overlap_schedules.txt).  The
+// job is therefore opt-in (VGAN_XX_RIDE=1 in v-gan_amd/trainer.py); kept because it is the piece a warm-operand carrier needs.
 #pragma once
 #include "gemm_bf3.hpp"
 #include "mmd_common.hpp"
@@ -23,13 +25,15 @@ struct XXJob {
     int ldd, row_batches, row_stride, ntiles, n;
 };
 
-// One 512-thread workgroup = two tiles (waves 0-3 and 4-7), `pair` = index of the pair.  lds: 2 x GemmBF3<64>::kLdsBytes.
-__device__ __forceinline__ void xx_tile_pair_body(const XXJob& job, int pair, char* lds, float* red /* [8] */) {
+// One tile per workgroup on 256 threads.  The host launch may use larger workgroups (the mask / projection kernel's have 512
+// threads): the surplus waves return at once -- s_barrier waits on the SURVIVING waves of a workgroup only, so the tile's
+// barriers keep working.  One tile per CU is the point: alone on a CU a tile takes ~7 us, two sharing one ~15 (measured with
+// tile PAIRS per workgroup: the carrying launch went from 9.4 to 18.2 us).  lds: GemmBF3<64>::kLdsBytes.
+__device__ __forceinline__ void xx_tile_body(const XXJob& job, int t, char* lds, float* red /* [4] */) {
     using G = GemmBF3<64>;
-    const int half = threadIdx.x >> 8, lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
-    const int t = 2 * pair + half;
-    const bool valid = t < job.ntiles;  // an odd tile count leaves one half idle: it runs a clamped tile for the barriers' sake
-    const TileDesc td = job.tiles[min(t, job.ntiles - 1)];
+    if (threadIdx.x >= kBlock) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TileDesc td = job.tiles[t];
     const int* map = job.rows;
     if (map != nullptr) map += (long)(job.cursor ? (long)(job.cursor[0] % (unsigned long long)job.row_batches) : 0l) * job.row_stride;
     auto row_of = [&](int g) { return map ? map[g] : g; };
@@ -43,8 +47,8 @@ __device__ __forceinline__ void xx_tile_pair_body(const XXJob& job, int pair, ch
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    G::template run<false>(job.Dh, job.Dl, job.ldd, job.Dh, job.Dl, job.ldd, td.r0, td.c0, td.rlim, td.clim, job.ldd,
-                           lds + half * G::kLdsBytes, nullptr, acc, map, map);
+    G::template run<false>(job.Dh, job.Dl, job.ldd, job.Dh, job.Dl, job.ldd, td.r0, td.c0, td.rlim, td.clim, job.ldd, lds, nullptr, acc, map,
+                           map);
     const float c2 = -1.4426950408889634f / (4.f * bw);
     float ksum = 0.f;
 #pragma unroll
@@ -57,11 +61,9 @@ __device__ __forceinline__ void xx_tile_pair_body(const XXJob& job, int pair, ch
         ksum += ok ? ((tt + t2) + (t4 + t8)) + t16 : 0.f;
     }
     ksum = wave_sum(ksum);
-    if (lane == 0) red[half * 4 + wave] = ksum;
+    if (lane == 0) red[wave] = ksum;
     __syncthreads();
-    if ((threadIdx.x & 255) == 0 && valid)
-        reinterpret_cast<float4*>(job.partial)[t] =
-            make_float4((red[half * 4] + red[half * 4 + 1]) + (red[half * 4 + 2] + red[half * 4 + 3]), 0.f, 0.f, 0.f);
+    if (threadIdx.x == 0) reinterpret_cast<float4*>(job.partial)[t] = make_float4((red[0] + red[1]) + (red[2] + red[3]), 0.f, 0.f, 0.f);
 }
 
 }  // namespace vgan

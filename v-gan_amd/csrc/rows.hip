@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* _
 // the split images of both the X row and the Y = U*X row: row-major (Zh, Zl) straight from registers, transposed
 // (ZTh, ZTl: [feature][row]) through an LDS tile, so that 8 rows leave as one 16-byte store per feature and image.  This
 // removes the separate preparation launch (~6 us of a ~120 us step at d = 784) and its 13 MB re-read of Z.
-// XX: workgroups past the row groups run the X-X tiles of the NEXT Gram launch (mmd_xx.hpp), two tiles each.
+// XX: workgroups past the row groups run the X-X tiles of this step's Gram (mmd_xx.hpp), one tile each.
 template <int NT, bool XX>
 __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
                                                                  int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ Z,
@@ -174,10 +174,10 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
                                                                  XXJob xx) {
     constexpr int R = 8;  // rows per workgroup = waves per workgroup (512 threads; 4 rows in 256 threads measured the same: 11.7 us)
     if constexpr (XX) {
-        __shared__ __attribute__((aligned(16))) char xx_lds[2 * GemmBF3<64>::kLdsBytes];
-        __shared__ float xx_red[8];
+        __shared__ __attribute__((aligned(16))) char xx_lds[GemmBF3<64>::kLdsBytes];
+        __shared__ float xx_red[4];
         if ((int)blockIdx.x >= mask_blocks) {  // block-uniform
-            xx_tile_pair_body(xx, blockIdx.x - mask_blocks, xx_lds, xx_red);
+            xx_tile_body(xx, blockIdx.x - mask_blocks, xx_lds, xx_red);
             return;
         }
     }
@@ -530,7 +530,7 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
         VGAN_CHECK_ARG(aligned16(j.Dh) && aligned16(j.Dl) && (reinterpret_cast<uintptr_t>(j.partial) & 15) == 0);
         xx = XXJob{j.Dh, j.Dl, j.dsq, rows, reinterpret_cast<const unsigned long long*>(row_cursor), reinterpret_cast<const TileDesc*>(j.tiles),
                    j.bw, j.partial, j.ldd, row_batches, row_stride, j.ntiles, n};
-        xx_blocks = (j.ntiles + 1) / 2;
+        xx_blocks = j.ntiles;
     }
     const dim3 grid(mask_blocks + xx_blocks), block(512);
     const size_t shmem = ZTh != nullptr ? (size_t)4 * 8 * (d + 8) * sizeof(unsigned short) : 0;

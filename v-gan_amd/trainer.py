@@ -263,15 +263,19 @@ class NoKLStepEngine:
         # bf16x3 mode, fused forward: the X-X tiles (sums only, independent of everything the step computes) ride in the mask /
         # projection launch as surplus workgroups, reading the batch's rows through the index table from split images of the
         # whole data set prepared ONCE here (csrc/mmd_xx.hpp).  The Gram launch keeps the XY and YY tiles: 392 instead of 528 at
-        # n = 1024, one round on the chip's 512 resident slots instead of two (24.2 -> 14.2 us).  Riding needs every workgroup
-        # of the launch resident at once at one per CU (the tile pairs hold 147 KB of LDS): 256 CUs.
+        # n = 1024, one round on the chip's 512 resident slots instead of two.  Riding wants every workgroup of the launch
+        # resident at once (a tile's workgroup holds 74 KB of LDS: two per CU).
         self.xx_ride = False
         self._xx = None
+        # MEASURED (MI355X, c3, same box, alternating runs): 8 266-8 319 steps/s riding vs 8 399-8 512 with the tiles inside the
+        # Gram launch.  The Gram does shrink (24.2 -> 17.5 us) but the carrying launch grows from 9.4 to 18.3 us: gathered from
+        # the data set's images the tiles' operand is HBM-cold (in the Gram it is the L2-hot image the forward has just
+        # written) and their K loop becomes latency-bound.  Opt-in (VGAN_XX_RIDE=1), off by default.
         if (self.fused_prepare and self.gram_tile == 64 and not self.overlap and self.rm_backward and
-                os.environ.get("VGAN_XX_RIDE", "1") == "1"):
+                os.environ.get("VGAN_XX_RIDE", "0") == "1"):
             split, n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=64, split_xx=True)
-            xx_pairs = (split.shape[0] - n_main + 1) // 2
-            self.xx_ride = xx_pairs > 0 and 8 * ((n // 8 + 7) // 8) + xx_pairs <= 256
+            xx_tiles = split.shape[0] - n_main
+            self.xx_ride = xx_tiles > 0 and 8 * ((n // 8 + 7) // 8) + xx_tiles <= 512  # two workgroups per CU (74 KB of LDS each)
         if self.xx_ride:
             i16 = dict(dtype=torch.int16, device=self.dev)
             rows_total = data.shape[0]
