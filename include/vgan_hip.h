@@ -76,12 +76,21 @@ int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nslabs, float* 
  *   the fp32 (and above all the split-bf16) operands; the step engine passes the data-set mean (vgan_col_mean).
  *   norm_split != 0: sqx/sqy are the norms of the split values hi + lo that vgan_mmd_bf3_prepare will produce from
  *   Zx/Zy (what vgan_mmd_gram_bf3 needs: L = s_i + s_j - 2 g is then |zhat_i - zhat_j|^2 exactly).
+ *   chain (may be NULL): Generator_big collapsed into one matrix (vgan_homogeneous_pack / vgan_gemm_grouped): the launch
+ *   computes logits = za . At4^T itself (za [n, ldza] = [z | 1 | 0-pad], At4 [d, ldat], e0 = round4(L + 1) columns used), one
+ *   wave per batch row, and `logits` is neither read nor written (may be NULL).  Needs the row-in-registers path: d % 4 == 0,
+ *   d <= 1024, aligned bases.  Removes the logits launch and 2 x n d x 4 bytes of traffic from the step.
  * ------------------------------------------------------------------------------------------- */
+typedef struct vgan_logits_chain {
+    const float* za;
+    const float* At4;
+    int32_t ldza, ldat, e0, pad;
+} vgan_logits_chain;
 int vgan_mask_project_forward(const float* logits, int ldl, const float* data, int ldd,
                               const int32_t* rows, const uint64_t* row_cursor, int row_batches,
                               int row_stride, int row_offset, float* S, float* U, float* Zx, float* Zy,
                               int ldz, float* sqx, float* sqy, int n, int d, const float* center,
-                              int norm_split, vgan_stream_t stream);
+                              int norm_split, const vgan_logits_chain* chain, vgan_stream_t stream);
 /* out[j] = mean over the rows of data[:, j] (float64 accumulation, fixed order): the `center` of the calls above. */
 int vgan_col_mean(const float* data, int ldd, int rows, int d, float* out, vgan_stream_t stream);
 /* out[i, :d] = data[rows[i], :d], sq[i] = |out[i]|^2 (sq may be NULL): batch rows a rank needs as
@@ -324,7 +333,8 @@ int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count, const vga
  * the data set, gathered by the same index table from split images prepared once per fit -- Dh, Dl [data rows, ldd] and dsq
  * (vgan_gather_rows_split over the whole data set with norm_split = 1).  tiles / ntiles: the X-X part of the tile table
  * (vgan_mmd_build_tiles, flags slot 0); partial: where their sums go (4 floats per tile, the layout vgan_mmd_finalize folds);
- * bw: the frozen bandwidth.  The Gram launch then covers the XY and YY tiles only. */
+ * bw: the frozen bandwidth.  The Gram launch then covers the XY and YY tiles only.
+ * chain (may be NULL; needs ZTh == NULL): as in vgan_mask_project_forward. */
 typedef struct vgan_xx_job {
     const uint16_t* Dh;
     const uint16_t* Dl;
@@ -338,7 +348,7 @@ int vgan_mask_project_forward_bf3(const float* logits, int ldl, const float* dat
                                   const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z,
                                   int ldz, float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh,
                                   uint16_t* ZTl, int kn, int n, int d, const float* center, int write_x,
-                                  const vgan_xx_job* xx, vgan_stream_t stream);
+                                  const vgan_xx_job* xx, const vgan_logits_chain* chain, vgan_stream_t stream);
 /* squared row norms sq[r] = |Z_r|^2 (for callers that assemble Z themselves) */
 int vgan_row_sqnorm(const float* Z, int ldz, float* sq, int rows, int p, vgan_stream_t stream);
 

@@ -88,9 +88,19 @@ class CpuOps:
     def col_mean(self, data, out):
         out[:data.shape[1]].copy_(torch.as_tensor(_np(data).astype(np.float64).mean(0)))
 
+    @staticmethod
+    def logits_chain(za, At4):
+        return (za, At4)
+
+    @staticmethod
+    def chain_fusable(n, d, *lds):
+        return d % 4 == 0 and d <= 1024 and all(int(v) % 4 == 0 for v in lds)
+
     def mask_project_forward(self, logits, data, rows, S, U, Zx, Zy, sqx, sqy, row_cursor=None, row_batches=1, row_stride=0,
-                             row_offset=0, center=None, norm_split=False):
-        n, d = logits.shape
+                             row_offset=0, center=None, norm_split=False, chain=None):
+        n, d = S.shape
+        if chain is not None:  # logits = [z|1] . At_4^T formed inside the launch
+            logits = torch.as_tensor((_np(chain[0]).astype(np.float64) @ _np(chain[1])[:d].astype(np.float64).T).astype(np.float32))
         u, s = orc.upper_softmax_forward(_np(logits).astype(np.float32))
         S.copy_(torch.as_tensor(s))
         if U is not None:
@@ -115,8 +125,8 @@ class CpuOps:
         return dict(Dh=Dh, Dl=Dl, dsq=dsq, tiles=tiles, bw=bw, partial=partial)
 
     def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
-                                 center=None, write_x=True, xx=None):
-        n, d = logits.shape
+                                 center=None, write_x=True, xx=None, chain=None):
+        n, d = S.shape
         if xx is not None:  # the X-X tiles of this batch from the data set's split images, gathered by the batch indices
             idx = torch.as_tensor(self._rows(rows, row_cursor, row_batches, row_stride, 0, n))
             Xh = torch.zeros(2 * n, xx["Dh"].shape[1], dtype=torch.int16)
@@ -127,12 +137,12 @@ class CpuOps:
             self.mmd_gram_bf3(Xh, Xl, sqx, n, xx["bw"], xx["tiles"], None, None, 0, xx["partial"])
         if write_x:
             self.mask_project_forward(logits, data, rows, S, None, Z[:n], Z[n:], sq[:n], sq[n:], row_cursor, row_batches, row_stride,
-                                      center=center, norm_split=True)
+                                      center=center, norm_split=True, chain=chain)
             self.mmd_bf3_prepare(Z, 2 * n, d, Zh, Zl, ZTh, ZTl)
         else:  # the X half is already in place (gather_rows_split ran ahead): only the Y half is produced
             assert ZTh is None
             self.mask_project_forward(logits, data, rows, S, None, None, Z[n:], None, sq[n:], row_cursor, row_batches, row_stride,
-                                      center=center, norm_split=True)
+                                      center=center, norm_split=True, chain=chain)
             self.mmd_bf3_prepare(Z[n:], n, d, Zh[n:], Zl[n:])
 
     @staticmethod

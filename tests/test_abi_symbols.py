@@ -65,7 +65,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.vgan_mmd_gram(null, 0, null, 0, 0, null, null, 0, 0, null, 0, 0, null, null) != 0
     assert lib.vgan_mmd_gram_bf3(null, null, 0, null, 0, null, null, 0, 64, null, null, 0, 0, null, null, 0, 0, 0, null, 0, 0, null) != 0
     assert lib.vgan_mask_project_forward_bf3(null, 0, null, 0, null, null, 1, 0, null, null, 0, null, null, null, 0, null, null, 0, 0, 0,
-                                             null, 1, null, null) != 0
+                                             null, 1, null, null, null) != 0
     assert lib.vgan_col_mean(null, 0, 0, 0, null, null) != 0
     assert lib.vgan_gemm_grouped(null, 0, null) != 0
     assert lib.vgan_adadelta_step(null, null, 1, 0, null, null, 0, 0.1, 0.9, 1e-6, 0.0, 1.0, null) != 0

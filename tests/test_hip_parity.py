@@ -1252,6 +1252,58 @@ def test_mask_project_forward_bf3_equals_two_launches(ops, n, d, centred):
     np.testing.assert_allclose(host(a["sq"]), host((zhat * zhat).sum(1)), rtol=2e-6)
 
 
+@pytest.mark.parametrize("n,d", [(1024, 784), (264, 1024), (72, 20), (128, 100)])
+def test_logits_inside_the_mask_forward_launch(ops, n, d):
+    """`chain=`: logits = [z|1] . At_4^T formed inside the mask / projection launch (both the fp32-mode kernel and the fused
+    bf16x3 one) against the separate logits launch followed by the same kernel: softmax to fp32 rounding (the two products
+    associate the sum over k differently), identical mask decisions except within rounding of the 1/d threshold, and the
+    operand images / norms following from them."""
+    rng = np.random.default_rng(n + 3 * d)
+    L = orc.latent_size(d)
+    e0 = (L + 1 + 3) // 4 * 4
+    za = torch.zeros(n, e0, device="cuda")
+    za[:, :L] = dev(rng.normal(size=(n, L)).astype(np.float32))
+    za[:, L] = 1.0
+    At4 = torch.zeros(d + 4, e0, device="cuda")
+    At4[:d, :L + 1] = dev((rng.normal(size=(d, L + 1)) * 0.5).astype(np.float32))
+    data = dev(rng.normal(size=(2 * n, d)).astype(np.float32))
+    perm = torch.as_tensor(rng.permutation(2 * n)[:n].astype(np.int32)).cuda()
+    center = torch.empty(d, device="cuda")
+    ops.col_mean(data, center)
+    logits = torch.empty(n, d, device="cuda")
+    ops.linear_forward(za, At4[:d], None, logits)
+    chain = ops.logits_chain(za, At4[:d])
+    dp, kp = (d + 3) // 4 * 4, (d + 63) // 64 * 64
+    i16 = dict(dtype=torch.int16, device="cuda")
+
+    def buffers():
+        return dict(S=torch.zeros(n, d, device="cuda"), Z=torch.zeros(2 * n, dp, device="cuda"), sq=torch.zeros(2 * n, device="cuda"),
+                    Zh=torch.zeros(2 * n, kp, **i16), Zl=torch.zeros(2 * n, kp, **i16))
+
+    for fused in (False, True):
+        a, b = buffers(), buffers()
+        if fused:
+            ops.mask_project_forward_bf3(logits, data, perm, a["S"], a["Z"], a["sq"], a["Zh"], a["Zl"], None, None, center=center)
+            ops.mask_project_forward_bf3(None, data, perm, b["S"], b["Z"], b["sq"], b["Zh"], b["Zl"], None, None, center=center, chain=chain)
+        else:
+            ops.mask_project_forward(logits, data, perm, a["S"], None, a["Z"][:n], a["Z"][n:], a["sq"][:n], a["sq"][n:], center=center)
+            ops.mask_project_forward(None, data, perm, b["S"], None, b["Z"][:n], b["Z"][n:], b["sq"][:n], b["sq"][n:], center=center, chain=chain)
+        torch.cuda.synchronize()
+        sa, sb = host(a["S"]).astype(np.float64), host(b["S"]).astype(np.float64)
+        np.testing.assert_allclose(sb, sa, rtol=5e-5, atol=1e-12)
+        tau = np.float32(1.0 / d)
+        flips = (host(a["S"]) >= tau) != (host(b["S"]) >= tau)
+        assert flips.sum() <= 4 and (np.abs(sa[flips] * d - 1.0) < 1e-4).all(), int(flips.sum())
+        same = ~flips.any(axis=1)
+        assert torch.equal(a["Z"][:n], b["Z"][:n]) and torch.equal(a["sq"][:n], b["sq"][:n])          # the X half does not see the logits
+        np.testing.assert_allclose(host(b["Z"][n:])[same], host(a["Z"][n:])[same], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(host(b["sq"][n:])[same], host(a["sq"][n:])[same], rtol=1e-4)
+        ref = host(za).astype(np.float64) @ host(At4[:d]).astype(np.float64).T
+        want = np.exp(ref - ref.max(1, keepdims=True))
+        want /= want.sum(1, keepdims=True)
+        np.testing.assert_allclose(sb, want, rtol=2e-5, atol=1e-12)
+
+
 def test_integration_stub_from_this_file():
     """The ctypes binding printed in INTEGRATION.md (section 2) is executed as written and checked against the oracle."""
     import re

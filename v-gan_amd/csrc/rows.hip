@@ -88,26 +88,78 @@ __global__ __launch_bounds__(kBlock) void mask_forward_kernel(const float* __res
 }
 
 
+// ---- logits inside the mask / projection launch (collapsed generator) ------------------------------------------------
+// Generator_big without activations is ONE matrix (trainer.py): logits = [z|1] . At_4^T with At_4 [d, e0] (e0 = round4(L + 1)).
+// With one wave per batch row and the row's logits living in registers anyway (NT float4 per lane), the product costs
+// NT * 4 * e0 FMAs per lane (832 at d = 784) -- less than the launch, the 3.2 MB write and the 3.2 MB re-read it replaces.
+// At_4 is staged transposed through LDS in chunks of 16 k ([k][column], read by 16-byte LDS ops: the lanes' float4 columns);
+// z_k is wave-uniform and comes through the scalar cache.
+struct LogitsChain {
+    const float* za;   // [n, ldza]: [z | 1 | 0-pad]
+    const float* At4;  // [d, ldat], first e0 columns
+    int ldza, ldat, e0;
+};
+constexpr int kChainK = 16;
+__host__ __device__ constexpr int chain_pitch(int d) { return ((d + 3) / 4) * 4 + 4; }  // 4 * pitch = 16 (mod 32): 2-way stores at worst
+
+template <int NT>
+__device__ __forceinline__ void chain_logits(const LogitsChain& ch, float* __restrict__ lds_at, int d, int row, bool row_ok, float4 (&v)[NT]) {
+    const int lane = threadIdx.x & 63, nq = d >> 2, pitch = chain_pitch(d);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* zr = ch.za + (long)(row_ok ? row : 0) * ch.ldza;
+    for (int kc = 0; kc < ch.e0; kc += kChainK) {
+        __syncthreads();  // the previous chunk has been consumed
+        for (int idx = threadIdx.x; idx < d * (kChainK / 4); idx += blockDim.x) {
+            const int col = idx / (kChainK / 4), kq = idx % (kChainK / 4), k = kc + 4 * kq;
+            const float4 a = k < ch.e0 ? *reinterpret_cast<const float4*>(ch.At4 + (long)col * ch.ldat + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            lds_at[(4 * kq + 0) * pitch + col] = a.x;
+            lds_at[(4 * kq + 1) * pitch + col] = a.y;
+            lds_at[(4 * kq + 2) * pitch + col] = a.z;
+            lds_at[(4 * kq + 3) * pitch + col] = a.w;
+        }
+        __syncthreads();
+        const int kw = min(kChainK, ch.e0 - kc);
+        for (int k = 0; k < kw; ++k) {
+            const float z = zr[kc + k];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int q = min(lane + 64 * t, nq - 1);
+                const float4 a = *reinterpret_cast<const float4*>(lds_at + k * pitch + 4 * q);
+                v[t].x = fmaf(z, a.x, v[t].x);
+                v[t].y = fmaf(z, a.y, v[t].y);
+                v[t].z = fmaf(z, a.z, v[t].z);
+                v[t].w = fmaf(z, a.w, v[t].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (lane + 64 * t >= nq) v[t] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+}
+
 // ---- fast paths: d % 4 == 0 and d <= 1024: the whole row lives in registers (NT float4 per lane), every global
 // access is 16 bytes per lane, and each row is read exactly once.
-template <int NT>
+template <int NT, bool CHAIN>
 __global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
                                                                  int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ U,
                                                                  float* __restrict__ Zx, float* __restrict__ Zy, int ldz,
                                                                  float* __restrict__ sqx, float* __restrict__ sqy, int n, int d,
-                                                                 const float* __restrict__ center, int norm_split) {
+                                                                 const float* __restrict__ center, int norm_split, LogitsChain ch) {
+    extern __shared__ __attribute__((aligned(16))) float chain_lds[];  // CHAIN: [kChainK][chain_pitch(d)]
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
-    if (i >= n) return;
     const int nq = d >> 2;
+    float4 v[NT], xv[NT], cv[NT];
+    if constexpr (CHAIN) chain_logits<NT>(ch, chain_lds, d, i, i < n, v);  // all waves take part in the staging barriers
+    if (i >= n) return;
     const float4* x4 = reinterpret_cast<const float4*>(logits + (long)i * ldl);
     const float4* xr4 = reinterpret_cast<const float4*>(data + rows(i) * ldd);
-    float4 v[NT], xv[NT], cv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int q = lane + 64 * t;
         const bool ok = q < nq;
-        v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if constexpr (!CHAIN) v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         xv[t] = xr4[min(q, nq - 1)];
         cv[t] = center ? reinterpret_cast<const float4*>(center)[min(q, nq - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -164,14 +216,14 @@ __global__ __launch_bounds__(kBlock) void mask_forward_vec_kernel(const float* _
 // (ZTh, ZTl: [feature][row]) through an LDS tile, so that 8 rows leave as one 16-byte store per feature and image.  This
 // removes the separate preparation launch (~6 us of a ~120 us step at d = 784) and its 13 MB re-read of Z.
 // XX: workgroups past the row groups run the X-X tiles of this step's Gram (mmd_xx.hpp), one tile each.
-template <int NT, bool XX>
+template <int NT, bool XX, bool CHAIN>
 __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ data,
                                                                  int ldd, RowSel rows, float* __restrict__ S, float* __restrict__ Z,
                                                                  int ldz, float* __restrict__ sq, unsigned short* __restrict__ Zh,
                                                                  unsigned short* __restrict__ Zl, int kp, unsigned short* __restrict__ ZTh,
                                                                  unsigned short* __restrict__ ZTl, int kn, int n, int d,
                                                                  const float* __restrict__ center, int write_x, int mask_blocks,
-                                                                 XXJob xx) {
+                                                                 XXJob xx, LogitsChain ch) {
     constexpr int R = 8;  // rows per workgroup = waves per workgroup (512 threads; 4 rows in 256 threads measured the same: 11.7 us)
     if constexpr (XX) {
         __shared__ __attribute__((aligned(16))) char xx_lds[GemmBF3<64>::kLdsBytes];
@@ -195,15 +247,18 @@ __global__ __launch_bounds__(512) void mask_forward_bf3_kernel(const float* __re
     const float tau = 1.0f / (float)d;
     {
         const int lr = wave, i = i0 + lr;
+        float4 v[NT];
+        // CHAIN (needs ZTh == NULL: the dynamic LDS region holds the At_4 chunk instead of the transposed tile)
+        if constexpr (CHAIN) chain_logits<NT>(ch, reinterpret_cast<float*>(tile), d, i, i < n, v);
         if (i < n) {
             const float4* x4 = reinterpret_cast<const float4*>(logits + (long)i * ldl);
             const float4* xr4 = reinterpret_cast<const float4*>(data + rows(i) * ldd);
-            float4 v[NT], xv[NT], cv[NT];
+            float4 xv[NT], cv[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int q = lane + 64 * t;
                 const bool ok = q < nq;
-                v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                if constexpr (!CHAIN) v[t] = ok ? x4[min(q, nq - 1)] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                 xv[t] = xr4[min(q, nq - 1)];
                 cv[t] = center ? reinterpret_cast<const float4*>(center)[min(q, nq - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -487,9 +542,16 @@ using namespace vgan;
 extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const float* data, int ldd, const int32_t* rows,
                                          const uint64_t* row_cursor, int row_batches, int row_stride, int row_offset, float* S,
                                          float* U, float* Zx, float* Zy, int ldz, float* sqx, float* sqy, int n, int d,
-                                         const float* center, int norm_split, vgan_stream_t stream) {
-    VGAN_CHECK_ARG(logits && data && S && Zy && sqy && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
+                                         const float* center, int norm_split, const vgan_logits_chain* chain, vgan_stream_t stream) {
+    VGAN_CHECK_ARG((logits || chain) && data && S && Zy && sqy && n > 0 && d > 0 && (logits == nullptr || ldl >= d) && ldd >= d && ldz >= d);
     VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && row_offset >= 0);
+    LogitsChain ch{};
+    if (chain != nullptr) {
+        VGAN_CHECK_ARG(chain->za && chain->At4 && chain->e0 > 0 && chain->e0 % 4 == 0 && chain->ldza >= chain->e0 && chain->ldat >= chain->e0 &&
+                       chain->ldat % 4 == 0 && aligned16(chain->At4));
+        ch = LogitsChain{chain->za, chain->At4, chain->ldza, chain->ldat, chain->e0};
+        if (logits == nullptr) { logits = chain->za; ldl = 4; }  // never dereferenced: keeps the alignment checks below meaningful
+    }
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
     const dim3 grid((n + kRowsPerBlock - 1) / kRowsPerBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
@@ -497,12 +559,26 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
                      aligned16(data) && aligned16(S) && (U == nullptr || aligned16(U)) && (Zx == nullptr || aligned16(Zx)) && aligned16(Zy) && (center == nullptr || aligned16(center));
     if (vec) {
         const int nt = (d / 4 + 63) / 64;
-#define VGAN_LAUNCH_FWD(NT) hipLaunchKernelGGL(mask_forward_vec_kernel<NT>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d, center, norm_split)
+        const size_t chain_bytes = (size_t)kChainK * chain_pitch(d) * sizeof(float);
+#define VGAN_LAUNCH_FWD(NT)                                                                                                               \
+    do {                                                                                                                                  \
+        if (chain != nullptr) {                                                                                                           \
+            if (chain_bytes > 64 * 1024)                                                                                                  \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_vec_kernel<NT, true>),                                \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_bytes);                                  \
+            hipLaunchKernelGGL((mask_forward_vec_kernel<NT, true>), grid, block, chain_bytes, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, \
+                               sqx, sqy, n, d, center, norm_split, ch);                                                                   \
+        } else                                                                                                                            \
+            hipLaunchKernelGGL((mask_forward_vec_kernel<NT, false>), grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, \
+                               sqy, n, d, center, norm_split, ch);                                                                        \
+    } while (0)
         if (nt == 1) VGAN_LAUNCH_FWD(1); else if (nt == 2) VGAN_LAUNCH_FWD(2); else if (nt == 3) VGAN_LAUNCH_FWD(3); else VGAN_LAUNCH_FWD(4);
 #undef VGAN_LAUNCH_FWD
-    } else
+    } else {
+        VGAN_CHECK_ARG(chain == nullptr);  // the in-launch logits need the row-in-registers path (d % 4 == 0, d <= 1024, aligned)
         hipLaunchKernelGGL(mask_forward_kernel<true>, grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d, center,
                            norm_split);
+    }
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -511,8 +587,16 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
                                              const uint64_t* row_cursor, int row_batches, int row_stride, float* S, float* Z, int ldz,
                                              float* sq, uint16_t* Zh, uint16_t* Zl, int kp, uint16_t* ZTh, uint16_t* ZTl, int kn,
                                              int n, int d, const float* center, int write_x, const vgan_xx_job* xxjob,
-                                             vgan_stream_t stream) {
-    VGAN_CHECK_ARG(logits && data && S && Z && sq && Zh && Zl && n > 0 && d > 0 && ldl >= d && ldd >= d && ldz >= d);
+                                             const vgan_logits_chain* chain, vgan_stream_t stream) {
+    VGAN_CHECK_ARG((logits || chain) && data && S && Z && sq && Zh && Zl && n > 0 && d > 0 && (logits == nullptr || ldl >= d) && ldd >= d &&
+                   ldz >= d);
+    LogitsChain ch{};
+    if (chain != nullptr) {
+        VGAN_CHECK_ARG(ZTh == nullptr && chain->za && chain->At4 && chain->e0 > 0 && chain->e0 % 4 == 0 && chain->ldza >= chain->e0 &&
+                       chain->ldat >= chain->e0 && chain->ldat % 4 == 0 && aligned16(chain->At4));
+        ch = LogitsChain{chain->za, chain->At4, chain->ldza, chain->ldat, chain->e0};
+        if (logits == nullptr) { logits = chain->za; ldl = 4; }
+    }
     VGAN_CHECK_ARG((ZTh == nullptr) == (ZTl == nullptr));
     VGAN_CHECK_ARG(row_batches >= 1 && row_stride >= 0 && kp >= d && kp % 64 == 0 && (ZTh == nullptr || (kn >= 2 * n && kn % 64 == 0)));
     VGAN_CHECK_ARG(write_x || ZTh == nullptr);  // the transposed images are always written whole
@@ -533,25 +617,28 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
         xx_blocks = j.ntiles;
     }
     const dim3 grid(mask_blocks + xx_blocks), block(512);
-    const size_t shmem = ZTh != nullptr ? (size_t)4 * 8 * (d + 8) * sizeof(unsigned short) : 0;
+    const size_t shmem = ZTh != nullptr ? (size_t)4 * 8 * (d + 8) * sizeof(unsigned short)
+                                        : (chain != nullptr ? (size_t)kChainK * chain_pitch(d) * sizeof(float) : 0);
     hipStream_t st = (hipStream_t)stream;
     const int nt = (d / 4 + 63) / 64;
     // (dynamic LDS above 64 KB -- d close to 1024 -- needs the opt-in; setting it is idempotent and cheap)
+#define VGAN_LAUNCH_K3(NT, XXF, CHF)                                                                                                \
+    do {                                                                                                                            \
+        if (shmem > 64 * 1024)                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_bf3_kernel<NT, XXF, CHF>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                      \
+        hipLaunchKernelGGL((mask_forward_bf3_kernel<NT, XXF, CHF>), grid, block, shmem, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, \
+                           Zh, Zl, kp, ZTh, ZTl, kn, n, d, center, write_x, mask_blocks, xx, ch);                                    \
+    } while (0)
 #define VGAN_LAUNCH_FWD3(NT)                                                                                                        \
     do {                                                                                                                            \
-        if (xx_blocks > 0) {                                                                                                        \
-            hipLaunchKernelGGL((mask_forward_bf3_kernel<NT, true>), grid, block, 0, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, Zh, \
-                               Zl, kp, ZTh, ZTl, kn, n, d, center, write_x, mask_blocks, xx);                                        \
-        } else {                                                                                                                    \
-            if (shmem > 64 * 1024)                                                                                                  \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_forward_bf3_kernel<NT, false>),                         \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
-            hipLaunchKernelGGL((mask_forward_bf3_kernel<NT, false>), grid, block, shmem, st, logits, ldl, data, ldd, sel, S, Z, ldz, sq, \
-                               Zh, Zl, kp, ZTh, ZTl, kn, n, d, center, write_x, mask_blocks, xx);                                    \
-        }                                                                                                                           \
+        if (xx_blocks > 0 && chain != nullptr) VGAN_LAUNCH_K3(NT, true, true);                                                      \
+        else if (xx_blocks > 0) VGAN_LAUNCH_K3(NT, true, false);                                                                    \
+        else if (chain != nullptr) VGAN_LAUNCH_K3(NT, false, true);                                                                 \
+        else VGAN_LAUNCH_K3(NT, false, false);                                                                                      \
     } while (0)
-    if (nt == 1) VGAN_LAUNCH_FWD3(1); else if (nt == 2) VGAN_LAUNCH_FWD3(2); else if (nt == 3) VGAN_LAUNCH_FWD3(3); else VGAN_LAUNCH_FWD3(4);
 #undef VGAN_LAUNCH_FWD3
+#undef VGAN_LAUNCH_K3
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -25,6 +25,11 @@ class GemmProblem(ctypes.Structure):
                 ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
+class LogitsChain(ctypes.Structure):
+    """struct vgan_logits_chain (include/vgan_hip.h): the collapsed generator evaluated inside the mask / projection launch."""
+    _fields_ = [("za", _p), ("At4", _p), ("ldza", ctypes.c_int32), ("ldat", ctypes.c_int32), ("e0", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
 class XXJob(ctypes.Structure):
     """struct vgan_xx_job (include/vgan_hip.h): the X-X Gram tiles riding in the mask / projection launch."""
     _fields_ = [("Dh", _p), ("Dl", _p), ("dsq", _p), ("tiles", _p), ("bw", _p), ("partial", _p), ("ldd", ctypes.c_int32),
@@ -57,7 +62,7 @@ SIGNATURES = {
     "vgan_linear_backward_input": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _i, _i64, _p, _i, _p, _i, _i, _i, _i, _i64, _p]),
     "vgan_reduce_slabs": (_i, [_p, _i64, _i, _p, _i64, _p]),
-    "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p]),
+    "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p, _p]),
     "vgan_col_mean": (_i, [_p, _i, _i, _i, _p, _p]),
     "vgan_gather_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
     "vgan_gather_rows_split": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p]),
@@ -89,7 +94,7 @@ SIGNATURES = {
     "vgan_adadelta_step_packed": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _i, _i, _i, _i, _u64, _p, _p]),
     "vgan_gemm_grouped": (_i, [_p, _i, _p]),
     "vgan_gemm_grouped_ex": (_i, [_p, _i, _p, _p]),
-    "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
+    "vgan_mask_project_forward_bf3": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p]),
     "vgan_mse_grad": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
     "vgan_sum_f64": (_i, [_p, _i, ctypes.c_double, _p, _i, _p]),
     "vgan_rbf_kernel_matrix": (_i, [_p, _i, _i, _i, _p, _f, _p, _i, _p]),

@@ -102,19 +102,35 @@ class HipOps:
         assert out.numel() >= d
         _lib.check(self.lib.vgan_col_mean(_ptr(data), data.stride(0), rows, d, _ptr(out), self._stream()), "vgan_col_mean")
 
+    @staticmethod
+    def logits_chain(za, At4):
+        """The collapsed generator as a job for mask_project_forward(_bf3) (`chain=`): logits = za . At4^T are formed inside that
+        launch.  za [n, e0] = [z | 1 | 0-pad], At4 [d, e0].  Raw pointers: the tensors must outlive every launch using the job."""
+        _mat(za, "za"), _mat(At4, "At4")
+        assert za.shape[1] == At4.shape[1]
+        return _lib.LogitsChain(_ptr(za), _ptr(At4), za.stride(0), At4.stride(0), za.shape[1], 0)
+
+    @staticmethod
+    def chain_fusable(n, d, *lds):
+        return d % 4 == 0 and d <= 1024 and all(int(v) % 4 == 0 for v in lds)
+
     def mask_project_forward(self, logits, data, rows, S, U, Zx, Zy, sqx, sqy, row_cursor=None, row_batches=1, row_stride=0,
-                             row_offset=0, center=None, norm_split=False):
+                             row_offset=0, center=None, norm_split=False, chain=None):
         """center [d]: subtracted from every row written to Zx / Zy; norm_split: sqx / sqy are the norms of the bf16 hi + lo
-        split of those rows (what mmd_gram_bf3 needs)."""
-        _mat(logits, "logits"), _mat(data, "data"), _mat(Zy, "Zy")
-        n, d = logits.shape
+        split of those rows (what mmd_gram_bf3 needs); chain: a logits_chain() -- `logits` is then not read (may be None)."""
+        _mat(data, "data"), _mat(Zy, "Zy"), _mat(S, "S")
+        n, d = S.shape
+        if logits is not None:
+            _mat(logits, "logits")
+            assert tuple(logits.shape) == (n, d)
         assert S.is_contiguous() and S.shape == (n, d) and (U is None or (U.is_contiguous() and U.shape == (n, d)))
         assert Zx is None or Zx.stride(0) == Zy.stride(0)
         if rows is not None:
             _vec(rows, "rows", torch.int32)
-        _lib.check(self.lib.vgan_mask_project_forward(_ptr(logits), logits.stride(0), _ptr(data), data.stride(0), _ptr(rows),
+        _lib.check(self.lib.vgan_mask_project_forward(_ptr(logits), logits.stride(0) if logits is not None else 0, _ptr(data), data.stride(0), _ptr(rows),
                                                       _ptr(row_cursor), int(row_batches), int(row_stride), int(row_offset), _ptr(S), _ptr(U), _ptr(Zx), _ptr(Zy), Zy.stride(0), _ptr(sqx), _ptr(sqy),
-                                                      n, d, _ptr(center), int(bool(norm_split)), self._stream()), "vgan_mask_project_forward")
+                                                      n, d, _ptr(center), int(bool(norm_split)),
+                                                      ctypes.byref(chain) if chain is not None else None, self._stream()), "vgan_mask_project_forward")
 
     def xx_job(self, Dh, Dl, dsq, tiles, bw, partial):
         """The X-X Gram tiles as a job for mask_project_forward_bf3 (`xx=`): Dh, Dl, dsq = split images / norms of the whole
@@ -124,16 +140,19 @@ class HipOps:
         return _lib.XXJob(_ptr(Dh), _ptr(Dl), _ptr(dsq), _ptr(tiles), _ptr(bw), _ptr(partial), Dh.stride(0), tiles.shape[0])
 
     def mask_project_forward_bf3(self, logits, data, rows, S, Z, sq, Zh, Zl, ZTh, ZTl, row_cursor=None, row_batches=1, row_stride=0,
-                                 center=None, write_x=True, xx=None):
+                                 center=None, write_x=True, xx=None, chain=None):
         """mask_project_forward + mmd_bf3_prepare in one launch (shape contract in include/vgan_hip.h; see bf3_fusable)."""
-        _mat(logits, "logits"), _mat(data, "data"), _mat(Z, "Z")
-        n, d = logits.shape
-        _lib.check(self.lib.vgan_mask_project_forward_bf3(_ptr(logits), logits.stride(0), _ptr(data), data.stride(0), _ptr(rows),
+        _mat(data, "data"), _mat(Z, "Z"), _mat(S, "S")
+        n, d = S.shape
+        if logits is not None:
+            _mat(logits, "logits")
+        _lib.check(self.lib.vgan_mask_project_forward_bf3(_ptr(logits), logits.stride(0) if logits is not None else 0, _ptr(data), data.stride(0), _ptr(rows),
                                                           _ptr(row_cursor), int(row_batches), int(row_stride), _ptr(S), _ptr(Z), Z.stride(0),
                                                           _ptr(sq), _ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(ZTh), _ptr(ZTl),
                                                           ZTh.stride(0) if ZTh is not None else 0,
                                                           n, d, _ptr(center), int(bool(write_x)),
-                                                          ctypes.byref(xx) if xx is not None else None, self._stream()),
+                                                          ctypes.byref(xx) if xx is not None else None,
+                                                          ctypes.byref(chain) if chain is not None else None, self._stream()),
                    "vgan_mask_project_forward_bf3")
 
     @staticmethod

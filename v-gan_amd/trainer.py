@@ -231,6 +231,11 @@ class NoKLStepEngine:
             self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
         self.fused_prepare = (self.bf3 and ops.bf3_fusable(n, d, self.logits.stride(0), data.stride(0), dp) and
                               os.environ.get("VGAN_FUSED_PREPARE", "1") == "1")
+        # collapsed generator: the logits product rides in the mask / projection launch (one wave per batch row, the row's logits
+        # live in its registers anyway): one launch and 2 n d x 4 bytes of traffic less per step.  VGAN_CHAIN_IN_MASK=0: separate.
+        self.chain_in_mask = (self.mode == "collapsed" and ops.chain_fusable(n, d, data.stride(0), dp) and
+                              (not self.bf3 or self.fused_prepare) and os.environ.get("VGAN_CHAIN_IN_MASK", "1") == "1")
+        self._chain = None
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         # Gram tile edge: the split-bf16 Gram has a 128x128 variant (half the L2 -> LDS bytes per flop, one 512-thread
         # workgroup per CU).  Measured: c5 330 vs 273 TFLOP/s algorithmic, c3 (136 tiles of 128) no gain (26.3 vs 25.6 us),
@@ -404,7 +409,8 @@ class NoKLStepEngine:
         Wt, At = self.Wt, self.At
         ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3)])
         ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
-        ops.linear_forward(self.za, At[4][:self.d], None, self.logits)
+        if not self.chain_in_mask:  # otherwise logits = [z|1] . At_4^T are formed inside the mask / projection launch
+            ops.linear_forward(self.za, At[4][:self.d], None, self.logits)
 
     def _generator_backward_update(self, dist):
         """dlogits -> parameter gradients -> (all-reduce) -> Adadelta."""
@@ -472,6 +478,12 @@ class NoKLStepEngine:
             ops.noise_normal(self.za, self.seed, self.step_counter, 0, cols=self.L, ones_col=self.L)
         self._generator_forward()
         rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
+        logits = self.logits
+        if self.chain_in_mask:
+            if self._chain is None:
+                self._chain = ops.logits_chain(self.za, self.At[4][:self.d])
+            rowsel["chain"] = self._chain
+            logits = None
         if self.fused_prepare:  # mask/projection and the bf16x3 operand split in one launch
             xx = None
             if self.xx_ride and self.has_bw:  # (before the bandwidth exists the first step runs these tiles after its calibration)
@@ -479,14 +491,14 @@ class NoKLStepEngine:
                     ntx = self.tiles.shape[0] - self.n_main
                     self._xx = ops.xx_job(self.Dh, self.Dl, self.dsq, self.tiles[self.n_main:], self.bw, self.partial[self.n_main:self.n_main + ntx])
                 xx = self._xx
-            ops.mask_project_forward_bf3(self.logits, self.data, self.perm, self.S, self.Z, self.sqn, self.Zh, self.Zl, self.ZTh, self.ZTl,
+            ops.mask_project_forward_bf3(logits, self.data, self.perm, self.S, self.Z, self.sqn, self.Zh, self.Zl, self.ZTh, self.ZTl,
                                          center=self.center, write_x=not self.x_ahead, xx=xx, **rowsel)
             return
         if self.x_ahead:  # the X half of Z / sq (and of the split images) is already in place
-            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, None, self.Z[n:], None, self.sqn[n:],
+            ops.mask_project_forward(logits, self.data, self.perm, self.S, None, None, self.Z[n:], None, self.sqn[n:],
                                      row_offset=0, center=self.center, norm_split=self.bf3, **rowsel)
         else:
-            ops.mask_project_forward(self.logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n], self.sqn[n:],
+            ops.mask_project_forward(logits, self.data, self.perm, self.S, None, self.Z[:n], self.Z[n:], self.sqn[:n], self.sqn[n:],
                                      row_offset=0, center=self.center, norm_split=self.bf3, **rowsel)
 
     def _calibrate(self):
