@@ -91,7 +91,9 @@ __global__ __launch_bounds__(kBlock) void mask_forward_kernel(const float* __res
 // ---- logits inside the mask / projection launch (collapsed generator) ------------------------------------------------
 // Generator_big without activations is ONE matrix (trainer.py): logits = [z|1] . At_4^T with At_4 [d, e0] (e0 = round4(L + 1)).
 // With one wave per batch row and the row's logits living in registers anyway (NT float4 per lane), the product costs
-// NT * 4 * e0 FMAs per lane (832 at d = 784) -- less than the launch, the 3.2 MB write and the 3.2 MB re-read it replaces.
+// NT * 4 * e0 FMAs per lane (832 at d = 784).  MEASURED on MI355X at d = 784: not a win -- every workgroup stages all of At_4
+// (163 KB) for its few rows, chunk after chunk behind barriers, and the launch grows by 12 us against the 5 us launch and
+// 6 MB of traffic it replaces.  The step engine keeps it opt-in (VGAN_CHAIN_IN_MASK=1, v-gan_amd/trainer.py).
 // At_4 is staged transposed through LDS in chunks of 16 k ([k][column], read by 16-byte LDS ops: the lanes' float4 columns);
 // z_k is wave-uniform and comes through the scalar cache.
 struct LogitsChain {
@@ -637,6 +639,7 @@ extern "C" int vgan_mask_project_forward_bf3(const float* logits, int ldl, const
         else if (chain != nullptr) VGAN_LAUNCH_K3(NT, false, true);                                                                 \
         else VGAN_LAUNCH_K3(NT, false, false);                                                                                      \
     } while (0)
+    if (nt == 1) VGAN_LAUNCH_FWD3(1); else if (nt == 2) VGAN_LAUNCH_FWD3(2); else if (nt == 3) VGAN_LAUNCH_FWD3(3); else VGAN_LAUNCH_FWD3(4);
 #undef VGAN_LAUNCH_FWD3
 #undef VGAN_LAUNCH_K3
     VGAN_CHECK_LAUNCH();

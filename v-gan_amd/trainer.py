@@ -231,10 +231,14 @@ class NoKLStepEngine:
             self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
         self.fused_prepare = (self.bf3 and ops.bf3_fusable(n, d, self.logits.stride(0), data.stride(0), dp) and
                               os.environ.get("VGAN_FUSED_PREPARE", "1") == "1")
-        # collapsed generator: the logits product rides in the mask / projection launch (one wave per batch row, the row's logits
-        # live in its registers anyway): one launch and 2 n d x 4 bytes of traffic less per step.  VGAN_CHAIN_IN_MASK=0: separate.
+        # collapsed generator, opt-in (VGAN_CHAIN_IN_MASK=1): the logits product inside the mask / projection launch (one wave per
+        # batch row, the row's logits live in its registers anyway): one launch and 2 n d x 4 bytes of traffic less per step.
+        # MEASURED (MI355X, c3, same box, alternating runs): 8 029-8 038 steps/s fused vs 8 371-8 455 separate (fp32 mode 5 873 vs
+        # 6 316).  Every workgroup has to stage all of At_4 (163 KB, transposed through LDS in four chunks, each a dependent
+        # global load + barrier) for its 8 rows: the carrying launch grows from 9.5 to 21.8 us, more than the 5.2 us launch it
+        # replaces.  Off by default.
         self.chain_in_mask = (self.mode == "collapsed" and ops.chain_fusable(n, d, data.stride(0), dp) and
-                              (not self.bf3 or self.fused_prepare) and os.environ.get("VGAN_CHAIN_IN_MASK", "1") == "1")
+                              (not self.bf3 or self.fused_prepare) and os.environ.get("VGAN_CHAIN_IN_MASK", "0") == "1")
         self._chain = None
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         # Gram tile edge: the split-bf16 Gram has a 128x128 variant (half the L2 -> LDS bytes per flop, one 512-thread
