@@ -56,6 +56,13 @@ int vgan_linear_backward_input(const float* dy, int lddy, const float* W, int ld
 int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int ldx, int x_nslabs,
                                 int64_t x_slab_stride, float* dW, int lddw, float* db, int n, int in,
                                 int out, int splits, int64_t slab_stride, vgan_stream_t stream);
+/* vgan_linear_backward_params (db == NULL, no slabs) for the training step's M_4 = dlogits^T [z|1] with the X-X tiles of the
+ * Gram (struct vgan_xx_job, declared below; identity row map: Dh / Dl / dsq are the step's own Zh / Zl / sq) riding in the
+ * launch as surplus workgroups.  Shape contract: the 16-wave tall-skinny kernel's (out, in, leading dimensions % 4 == 0,
+ * aligned bases, n >= 256, at most 32 64x64 output tiles). */
+struct vgan_xx_job;
+int vgan_linear_backward_params_xx(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int n, int in,
+                                   int out, const struct vgan_xx_job* xx, vgan_stream_t stream);
 /* dst[i] = sum over s < nslabs of src[s*slab_stride + i], in ascending s (bitwise reproducible) */
 int vgan_reduce_slabs(const float* src, int64_t slab_stride, int nslabs, float* dst, int64_t count,
                       vgan_stream_t stream);
@@ -215,6 +222,11 @@ typedef struct vgan_finalize_job {
     uint64_t* step_counter;
     int32_t ntiles, chunks, n, d;
     float weight, accum_scale;
+    /* mode 0: the whole tail.  The X-X tiles of the Gram may be computed LATER in the step than the launch the tail rides in
+     * (vgan_linear_backward_params_xx); the tail is then split: mode 1 = everything but the X-X block sum, over tiles
+     * [0, ntiles_main) -- column keys, Sxy, Syy, the step counter; the loss so far is parked in stats[3] -- and mode 2 = the
+     * X-X block sum over tiles [ntiles_main, ntiles), the loss and its accumulator (rides in vgan_gemm_grouped_ex, `fold`). */
+    int32_t mode, ntiles_main;
 } vgan_finalize_job;
 /* dZ[i - wrow0, :] = 2 (rowsum(Wg_i) z_i - Wg_i . Z) for the nr rows starting at wrow0;
  * if mul != NULL the result is multiplied elementwise by mul[i - wrow0, :] (the `U * batch`
@@ -294,7 +306,8 @@ int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_
  *             weight w_packed[row*ldp + col] are updated in place (C_i is still written).  None of the launch's operands
  *             may alias an updated w_packed.  g_extra != NULL: one more layer, layer[count], whose packed gradient already
  *             sits in memory (row stride ld_extra) is updated element-wise by surplus workgroups;
- *   noise     next_noise != NULL: the next step's noise draw, as in vgan_adadelta_step_packed. */
+ *   noise     next_noise != NULL: the next step's noise draw, as in vgan_adadelta_step_packed;
+ *   fold      a vgan_finalize_job run by one surplus workgroup (the late half of a split step tail). */
 typedef struct vgan_adadelta_layer {
     float* w_packed;
     int64_t off_w, off_b;
@@ -316,6 +329,7 @@ typedef struct vgan_grouped_extras {
     int32_t noise_rows, noise_cols, noise_ld, noise_ones_col;
     uint64_t seed;
     const uint64_t* step_counter;
+    const vgan_finalize_job* fold; /* NULL, or a step-tail job (normally mode 2) run by one surplus workgroup */
 } vgan_grouped_extras;
 int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count, const vgan_grouped_extras* extras,
                          vgan_stream_t stream);

@@ -197,11 +197,32 @@ class CpuOps:
         self.colmax(S, row_offset, None, part[:d], from_softmax)
 
     def mmd_finalize(self, partial, tiles, colpart, chunks, colkey, n, d, weight, stats, loss, loss_accum=None, accum_scale=1.0,
-                     step_counter=None):
-        self.mmd_reduce(partial, tiles, stats, True)
-        if colpart is not None:
-            colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
-        self.mmd_loss(stats, colkey if colpart is not None else None, n, d, weight, loss, loss_accum, accum_scale, step_counter)
+                     step_counter=None, mode=0, ntiles_main=0):
+        if mode == 0:
+            self.mmd_reduce(partial, tiles, stats, True)
+            if colpart is not None:
+                colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
+            self.mmd_loss(stats, colkey if colpart is not None else None, n, d, weight, loss, loss_accum, accum_scale, step_counter)
+            return
+        # split tail (include/vgan_hip.h): mode 1 = all but the X-X block sum, mode 2 = the X-X block sum and the loss
+        st = torch.zeros(4, dtype=torch.float64)
+        if mode == 1:
+            self.mmd_reduce(partial[:ntiles_main], tiles[:ntiles_main], st, True)
+            v = (-2.0 * float(st[1]) + float(st[2])) / (float(n) * n)
+            if colpart is not None:
+                colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
+                vals = (_np(colkey).view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32)
+                v += weight * float(np.mean(1.0 - vals.astype(np.float64)))
+            stats[1], stats[2], stats[3] = float(st[1]), float(st[2]), v
+            if step_counter is not None:
+                step_counter += 1
+        else:
+            self.mmd_reduce(partial[ntiles_main:], tiles[ntiles_main:], st, True)
+            stats[0] = float(st[0])
+            v = float(stats[3]) + float(st[0]) / (float(n) * n)
+            loss.fill_(v)
+            if loss_accum is not None:
+                loss_accum += v * accum_scale
 
     def finalize_job(self, *args, **kw):
         return (args, kw)
@@ -389,7 +410,12 @@ class CpuOps:
     def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
         return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 
-    def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None):
+    def linear_backward_params_xx(self, dy, x, dW, xx):
+        self.linear_backward_params(dy, x, dW, None)
+        n = xx["Dh"].shape[0] // 2
+        self.mmd_gram_bf3(xx["Dh"], xx["Dl"], xx["dsq"], n, xx["bw"], xx["tiles"], None, None, 0, xx["partial"])
+
+    def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None, fold=None):
         outs = []
         for kind, A, B, C in problems:  # all reads before any write: the products are independent by contract
             a, b = _np(A).astype(np.float64), _np(B).astype(np.float64)
@@ -401,6 +427,8 @@ class CpuOps:
             copy[1].copy_(copy[0])
         for (_, _, _, C), r in zip(problems, outs):
             C.copy_(torch.as_tensor(r))
+        if fold is not None:
+            self.mmd_finalize(*fold[0], **fold[1])
         if adadelta is not None:
             a = adadelta
             grads = [C for _, _, _, C in problems] + ([a["extra_grad"]] if a.get("extra_grad") is not None else [])

@@ -114,6 +114,32 @@ def test_xx_tiles_riding_in_the_forward_launch_equal_the_gram_launch(monkeypatch
     assert torch.equal(res["1"][1], res["0"][1])  # the X-X sums feed the reported loss only, never a gradient
 
 
+def test_xx_tiles_in_the_m4_launch_with_split_step_tail(monkeypatch):
+    """bf16x3 mode: the X-X tiles computed inside the M_4 launch (two launches after the MMD backward that carries the step
+    tail) with the tail split in two -- everything but the X-X block sum early, the X-X sum and the loss in the first chain
+    launch of the backward -- give the same per-step losses, statistics and parameters as the unsplit schedule (CPU provider,
+    across an epoch boundary)."""
+    g = load_golden("f3_traj_c1.npz")
+    res = {}
+    for late in ("1", "0"):
+        monkeypatch.setenv("VGAN_XX_IN_M4", late)
+        eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["data"], 128, 10, mmd_precision="bf16x3")
+        assert eng.xx_in_m4 == (late == "1")
+        losses, sxx = [], []
+        for t in range(13):
+            if t % 10 == 0:
+                eng.set_epoch_batches(torch.as_tensor(g["idx"][t:t + 10].astype(np.int64)))
+            eng.set_noise(torch.as_tensor(g["noise"][t]))
+            eng.step()
+            losses.append(float(eng.loss))
+            sxx.append(float(eng.stats[0]))
+        res[late] = (np.array(losses), np.array(sxx), eng.fp.flat.clone(), float(eng.loss_accum))
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(res["1"][1], res["0"][1], rtol=1e-6)
+    np.testing.assert_allclose(res["1"][0], g["losses"][:13], rtol=0, atol=1e-4)
+    assert torch.equal(res["1"][2], res["0"][2]) and abs(res["1"][3] - res["0"][3]) < 1e-5
+
+
 def test_engine_bf16x3_precision_mode_vs_reference_fixture():
     """Split-bf16 MMD mode (emulated on the CPU stand-in with torch.bfloat16 roundings): the step still meets the loss bar."""
     g = load_golden("f2_step_c2.npz")

@@ -5,6 +5,7 @@
 // on each other share a launch.  Per problem the library picks the tile engine: 32x32 tiles with K split over the waves
 // (GemmTileKS) when the 64x64 grid would be a handful of long-K tiles, 64x64x32 tiles otherwise.
 #include "gemm_core.hpp"
+#include "mmd_common.hpp"
 #include "optim_common.hpp"
 
 namespace vgan {
@@ -34,6 +35,8 @@ struct GroupedExtras {
     int zrows, zcols, zld, zones;
     unsigned long long seed;
     const unsigned long long* step_counter;
+    int fold_blocks;
+    vgan_finalize_job fold;
 };
 
 // the optimiser step of one element of a packed gradient image [dW | db]: (row, col) -> flat parameter index
@@ -101,7 +104,12 @@ __device__ __forceinline__ void grouped_extra_jobs(const GroupedExtras& x, int b
         return;
     }
     b -= x.extra_blocks;
-    if (b < x.noise_blocks) noise_normal_body(x.z, x.zrows, x.zcols, x.zld, x.zones, x.seed, x.step_counter, 0ull, b, x.noise_blocks);
+    if (b < x.noise_blocks) {
+        noise_normal_body(x.z, x.zrows, x.zcols, x.zld, x.zones, x.seed, x.step_counter, 0ull, b, x.noise_blocks);
+        return;
+    }
+    b -= x.noise_blocks;
+    if (b < x.fold_blocks) finalize_body(x.fold);
 }
 
 template <int LA, int LB, int VEC, bool EPI>
@@ -269,15 +277,20 @@ extern "C" int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count
             x.step_counter = reinterpret_cast<const unsigned long long*>(e.step_counter);
             x.noise_blocks = extra_grid(((long)e.noise_rows * e.noise_cols + 3) / 4);
         }
+        if (e.fold != nullptr) {
+            VGAN_CHECK_ARG(finalize_job_ok(*e.fold));
+            x.fold = *e.fold;
+            x.fold_blocks = 1;
+        }
     }
-    const int surplus = x.copy_blocks + x.extra_blocks + x.noise_blocks;
+    const int surplus = x.copy_blocks + x.extra_blocks + x.noise_blocks + x.fold_blocks;
     // all products long-K and few tiles: one 1024-thread launch with every problem on 32x32 tiles (no optimiser epilogue there)
     int kmin = problems[0].k, t32 = 0;
     for (int i = 0; i < count; ++i) {
         kmin = problems[i].k < kmin ? problems[i].k : kmin;
         t32 += ((problems[i].m + 31) / 32) * ((problems[i].n + 31) / 32);
     }
-    if (vec && kmin >= 96 && t32 <= 256 && !epi && x.noise_blocks == 0) {
+    if (vec && kmin >= 96 && t32 <= 256 && !epi && x.noise_blocks == 0) {  // (copy and fold jobs ride in this variant too)
         int acc = 0;
         for (int i = 0; i < count; ++i) {
             g.ks[i] = 1;

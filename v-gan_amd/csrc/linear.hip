@@ -2,6 +2,7 @@
 // Reference ops replaced: src/models/Generator.py:61-66, src/models/Detector.py:8-13,24-29
 // (F.linear == addmm forward; autograd's two mm per layer backward).
 #include "gemm_core.hpp"
+#include "mmd_xx.hpp"
 
 namespace vgan {
 
@@ -121,6 +122,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_bwd_params_ks
         if (row < out && col < in) dW[(long)row * lddw + col] = o[rr];
     }
 }
+// The same tall-skinny product with the X-X tiles of the Gram riding behind it (mmd_xx.hpp): the M_4 launch of the training
+// step is long (8.5 us), occupies ~50 of the 256 CUs and is not L2-bound, and by then the X half of the split operand is
+// L2 / Infinity-Cache warm -- the carrier the cold-operand experiments of mmd_xx.hpp were missing.  1-D grid: product tiles
+// first, then one X-X tile per workgroup (its 12 surplus waves return at once).
+__global__ __launch_bounds__(1024, 1) void linear_bwd_params_ks_xx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                                         int ldx, float* __restrict__ dW, int lddw, int n, int in, int out,
+                                                                         int gx, int ptiles, XXJob xx) {
+    using G = GemmTileKS<KSBK, MC, MC, 4, 16>;
+    constexpr int kBytes = G::kLdsFloats * 4 > GemmBF3<64>::kLdsBytes ? G::kLdsFloats * 4 : GemmBF3<64>::kLdsBytes;
+    __shared__ __attribute__((aligned(16))) char raw[kBytes];
+    __shared__ float xx_red[4];
+    if ((int)blockIdx.x >= ptiles) {  // block-uniform
+        xx_tile_body(xx, blockIdx.x - ptiles, raw, xx_red);
+        return;
+    }
+    float* lds = reinterpret_cast<float*>(raw);
+    const int m0 = (blockIdx.x / gx) * 32, n0 = (blockIdx.x % gx) * 32;
+    float o[G::NR];
+    G::run(dy, lddy, x, ldx, m0, n0, out, in, n, lds, o);
+    const int col = n0 + G::col_of();
+#pragma unroll
+    for (int rr = 0; rr < G::NR; ++rr) {
+        const int row = m0 + G::row_of(rr);
+        if (row < out && col < in) dW[(long)row * lddw + col] = o[rr];
+    }
+}
+
 // heuristic: few 64x64 tiles and a long contraction -> the K loop of a tile is the critical path
 static inline bool use_ks(int rows, int cols, int k) {
     const long tiles64 = (long)((rows + 63) / 64) * ((cols + 63) / 64);
@@ -197,6 +225,23 @@ extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const floa
     if (x_nslabs > 1) { if (vec) VGAN_BWP(4, true); else VGAN_BWP(1, true); }
     else { if (vec) VGAN_BWP(4, false); else VGAN_BWP(1, false); }
 #undef VGAN_BWP
+    VGAN_CHECK_LAUNCH();
+    return VGAN_OK;
+}
+
+extern "C" int vgan_linear_backward_params_xx(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int n, int in,
+                                              int out, const vgan_xx_job* xxjob, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(dy && x && dW && xxjob && n > 0 && in > 0 && out > 0 && lddy >= out && ldx >= in && lddw >= in);
+    const vgan_xx_job& j = *xxjob;
+    VGAN_CHECK_ARG(j.Dh && j.Dl && j.dsq && j.tiles && j.bw && j.partial && j.ntiles > 0 && j.ldd % 64 == 0 && aligned16(j.Dh) && aligned16(j.Dl) &&
+                   (reinterpret_cast<uintptr_t>(j.partial) & 15) == 0);
+    // the shape contract of the 16-wave tall-skinny kernel (what vgan_linear_backward_params picks for the step's M_4 product)
+    VGAN_CHECK_ARG((out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldx % 4 == 0) && aligned16(dy) && aligned16(x) && n >= 256 &&
+                   use_ks(out, in, n));
+    const int gx = (in + 31) / 32, gy = (out + 31) / 32;
+    const XXJob xx{j.Dh, j.Dl, j.dsq, nullptr, nullptr, reinterpret_cast<const TileDesc*>(j.tiles), j.bw, j.partial, j.ldd, 1, 0, j.ntiles, 0};
+    hipLaunchKernelGGL(linear_bwd_params_ks_xx_kernel, dim3(gx * gy + j.ntiles), dim3(1024), 0, (hipStream_t)stream, dy, lddy, x, ldx, dW, lddw, n,
+                       in, out, gx, gx * gy, xx);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }

@@ -519,7 +519,7 @@ extern "C" int vgan_mmd_finalize(const float* partial, const int32_t* tiles, int
                                  uint64_t* colkey, int n, int d, float weight, double* stats, float* loss, float* loss_accum,
                                  float accum_scale, uint64_t* step_counter, vgan_stream_t stream) {
     const vgan_finalize_job job{partial, tiles, colpart, colkey, stats, loss, loss_accum, step_counter, ntiles, chunks, n, d, weight,
-                                accum_scale};
+                                accum_scale, 0, 0};
     VGAN_CHECK_ARG(finalize_job_ok(job));
     hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, job);
     VGAN_CHECK_LAUNCH();

@@ -25,7 +25,7 @@ struct ColmaxJob {
 __device__ __forceinline__ void finalize_body(const vgan_finalize_job& job) {
     const float* __restrict__ partial = job.partial;
     const TileDesc* __restrict__ tiles = reinterpret_cast<const TileDesc*>(job.tiles);
-    const unsigned long long* __restrict__ colpart = reinterpret_cast<const unsigned long long*>(job.colpart);
+    const unsigned long long* colpart = reinterpret_cast<const unsigned long long*>(job.colpart);
     unsigned long long* __restrict__ colkey = reinterpret_cast<unsigned long long*>(job.colkey);
     double* __restrict__ stats = job.stats;
     float* __restrict__ loss = job.loss;
@@ -33,10 +33,15 @@ __device__ __forceinline__ void finalize_body(const vgan_finalize_job& job) {
     unsigned long long* __restrict__ step_counter = reinterpret_cast<unsigned long long*>(job.step_counter);
     const int ntiles = job.ntiles, chunks = job.chunks, n = job.n, d = job.d;
     const float weight = job.weight, accum_scale = job.accum_scale;
+    // split tail (vgan_finalize_job.mode): 1 = all but the X-X block sum, tiles [0, ntiles_main); 2 = the X-X block sum, tiles
+    // [ntiles_main, ntiles), and the loss.  stats[3] carries the loss-so-far from 1 to 2 in double precision.
+    const int mode = job.mode;
+    const int t_lo = mode == 2 ? job.ntiles_main : 0, t_hi = mode == 1 ? job.ntiles_main : ntiles;
+    if (mode == 2) colpart = nullptr;
 
     __shared__ double red[16][5];  // up to 1024 threads
     double s[5] = {0, 0, 0, 0, 0};  // Sxx, Sxy, Syy, sumL, penalty
-    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+    for (int t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) {
         const int fl = tiles[t].flags;
         const double w = (fl & VGAN_TF_TWICE) ? 2.0 : 1.0;
         const float4 pv = reinterpret_cast<const float4*>(partial)[t];
@@ -69,18 +74,32 @@ __device__ __forceinline__ void finalize_body(const vgan_finalize_job& job) {
         const int nw = blockDim.x >> 6;
         for (int w = 0; w < nw; ++w)
             for (int q = 0; q < 5; ++q) t[q] += red[w][q];
-        for (int q = 0; q < 4; ++q) stats[q] = t[q];
         const double nn = (double)n * (double)n;
-        const double v = (t[0] - 2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
-        loss[0] = (float)v;
-        if (loss_accum) loss_accum[0] += (float)(v * (double)accum_scale);
-        if (step_counter) step_counter[0] += 1ull;
+        if (mode == 1) {
+            stats[1] = t[1];
+            stats[2] = t[2];
+            stats[3] = (-2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
+            if (step_counter) step_counter[0] += 1ull;
+        } else {
+            double v;
+            if (mode == 2) {
+                stats[0] = t[0];
+                v = stats[3] + t[0] / nn;
+            } else {
+                for (int q = 0; q < 4; ++q) stats[q] = t[q];
+                v = (t[0] - 2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
+                if (step_counter) step_counter[0] += 1ull;
+            }
+            loss[0] = (float)v;
+            if (loss_accum) loss_accum[0] += (float)(v * (double)accum_scale);
+        }
     }
 }
 
 inline bool finalize_job_ok(const vgan_finalize_job& j) {
     return j.partial && j.tiles && j.ntiles > 0 && j.stats && j.loss && j.n > 0 && j.d > 0 &&
-           (j.colpart == nullptr || (j.colkey != nullptr && j.chunks > 0));
+           (j.colpart == nullptr || (j.colkey != nullptr && j.chunks > 0)) && j.mode >= 0 && j.mode <= 2 &&
+           (j.mode == 0 || (j.ntiles_main >= 0 && j.ntiles_main <= j.ntiles));
 }
 
 }  // namespace vgan

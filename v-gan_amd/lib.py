@@ -16,7 +16,7 @@ class FinalizeJob(ctypes.Structure):
     """struct vgan_finalize_job (include/vgan_hip.h): the step tail riding in a backward launch."""
     _fields_ = [("partial", _p), ("tiles", _p), ("colpart", _p), ("colkey", _p), ("stats", _p), ("loss", _p), ("loss_accum", _p),
                 ("step_counter", _p), ("ntiles", ctypes.c_int32), ("chunks", ctypes.c_int32), ("n", ctypes.c_int32),
-                ("d", ctypes.c_int32), ("weight", _f), ("accum_scale", _f)]
+                ("d", ctypes.c_int32), ("weight", _f), ("accum_scale", _f), ("mode", ctypes.c_int32), ("ntiles_main", ctypes.c_int32)]
 
 
 class GemmProblem(ctypes.Structure):
@@ -48,7 +48,7 @@ class GroupedExtras(ctypes.Structure):
                 ("p", _p), ("sq_avg", _p), ("acc_delta", _p), ("lr", _f), ("rho", _f), ("eps", _f), ("weight_decay", _f),
                 ("grad_scale", _f), ("ld_extra", ctypes.c_int32), ("layer", AdadeltaLayer * 5), ("g_extra", _p), ("next_noise", _p),
                 ("noise_rows", ctypes.c_int32), ("noise_cols", ctypes.c_int32), ("noise_ld", ctypes.c_int32),
-                ("noise_ones_col", ctypes.c_int32), ("seed", _u64), ("step_counter", _p)]
+                ("noise_ones_col", ctypes.c_int32), ("seed", _u64), ("step_counter", _p), ("fold", _p)]
 
 
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
@@ -61,6 +61,7 @@ SIGNATURES = {
     "vgan_linear_forward": (_i, [_p, _i, _i, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_input": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _i, _i64, _p, _i, _p, _i, _i, _i, _i, _i64, _p]),
+    "vgan_linear_backward_params_xx": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "vgan_reduce_slabs": (_i, [_p, _i64, _i, _p, _i64, _p]),
     "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p, _p]),
     "vgan_col_mean": (_i, [_p, _i, _i, _i, _p, _p]),

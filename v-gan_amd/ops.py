@@ -89,6 +89,15 @@ class HipOps:
                                                         _ptr(dW), dW.stride(0), _ptr(db), n, kin, out, int(splits), int(slab_stride),
                                                         self._stream()), "vgan_linear_backward_params")
 
+    def linear_backward_params_xx(self, dy, x, dW, xx):
+        """linear_backward_params (no bias, no slabs) with an xx_job() riding in the launch (the step's M_4 product)."""
+        _mat(dy, "dy"), _mat(x, "x"), _mat(dW, "dW")
+        n, out = dy.shape
+        kin = x.shape[1]
+        assert x.shape[0] == n and dW.shape == (out, kin)
+        _lib.check(self.lib.vgan_linear_backward_params_xx(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dW), dW.stride(0), n, kin, out,
+                                                           ctypes.byref(xx), self._stream()), "vgan_linear_backward_params_xx")
+
     def reduce_slabs(self, src, slab_stride, nslabs, dst):
         _vec(dst, "dst")
         _lib.check(self.lib.vgan_reduce_slabs(_ptr(src), int(slab_stride), int(nslabs), _ptr(dst), dst.numel(), self._stream()),
@@ -214,11 +223,13 @@ class HipOps:
                                               float(accum_scale), _ptr(step_counter), self._stream()), "vgan_mmd_finalize")
 
     def finalize_job(self, partial, tiles, colpart, chunks, colkey, n, d, weight, stats, loss, loss_accum=None, accum_scale=1.0,
-                     step_counter=None):
-        """The arguments of mmd_finalize as a job for mmd_backward / mmd_backward_bf3 (`finalize=`).  The job holds raw device
-        pointers: the tensors must outlive every launch (and graph replay) that uses it."""
+                     step_counter=None, mode=0, ntiles_main=0):
+        """The arguments of mmd_finalize as a job for mmd_backward / mmd_backward_bf3 (`finalize=`) or gemm_grouped (`fold=`).
+        mode 1 / 2: the two halves of a split tail (include/vgan_hip.h: the X-X block sum arrives later in the step).  The job
+        holds raw device pointers: the tensors must outlive every launch (and graph replay) that uses it."""
         return _lib.FinalizeJob(_ptr(partial), _ptr(tiles), _ptr(colpart), _ptr(colkey), _ptr(stats), _ptr(loss), _ptr(loss_accum),
-                                _ptr(step_counter), tiles.shape[0], int(chunks), int(n), int(d), float(weight), float(accum_scale))
+                                _ptr(step_counter), tiles.shape[0], int(chunks), int(n), int(d), float(weight), float(accum_scale),
+                                int(mode), int(ntiles_main))
 
     def mask_from_softmax(self, S, U):
         _mat(S, "S"), _mat(U, "U")
@@ -347,14 +358,15 @@ class HipOps:
         """Tile edge (64 / 128) mmd_backward_bf3 runs for this shape (host-side query of the library's rule)."""
         return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 
-    def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None):
+    def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None, fold=None):
         """problems: up to 4 tuples (kind, A, B, C) with kind in "NN" (C = A.B), "NT" (C = A.B^T), "TN" (C = A^T.B); 2-D float32
         tensors with unit inner stride.  One launch; the products must not depend on each other.  Jobs that may ride in the
         launch (vgan_gemm_grouped_ex):
           copy = (src, dst)             contiguous float32 tensors of equal size, dst <- src;
           adadelta = dict(p, sq, acc, lr, rho, eps, weight_decay, grad_scale, layers=[(w_packed, off_w, off_b, out, in) per
                      problem (+ one more with extra_grad)], extra_grad=None): the optimiser update in the products' epilogue;
-          noise = dict(next_noise, noise_cols, noise_ones_col, seed, step_counter): the next step's noise draw."""
+          noise = dict(next_noise, noise_cols, noise_ones_col, seed, step_counter): the next step's noise draw;
+          fold = a finalize_job() run by one surplus workgroup (the late half of a split step tail)."""
         assert 1 <= len(problems) <= _lib.GEMM_MAX_GROUP
         arr = (_lib.GemmProblem * len(problems))()
         for q, (kind, A, B, C) in zip(arr, problems):
@@ -370,7 +382,7 @@ class HipOps:
             assert k == k2 and tuple(C.shape) == (m, n), (kind, tuple(A.shape), tuple(B.shape), tuple(C.shape))
             q.a, q.b, q.c, q.kind, q.m, q.n, q.k = A.data_ptr(), B.data_ptr(), C.data_ptr(), code, m, n, k
             q.lda, q.ldb, q.ldc = A.stride(0), B.stride(0), C.stride(0)
-        if copy is None and adadelta is None and noise is None:
+        if copy is None and adadelta is None and noise is None and fold is None:
             _lib.check(self.lib.vgan_gemm_grouped(arr, len(problems), self._stream()), "vgan_gemm_grouped")
             return
         x = _lib.GroupedExtras()
@@ -399,6 +411,8 @@ class HipOps:
             x.next_noise, x.noise_rows, x.noise_ld = z.data_ptr(), z.shape[0], z.stride(0)
             x.noise_cols, x.noise_ones_col = int(noise["noise_cols"]), int(noise["noise_ones_col"])
             x.seed, x.step_counter = int(noise["seed"]) & 0xFFFFFFFFFFFFFFFF, noise["step_counter"].data_ptr()
+        if fold is not None:
+            x.fold = ctypes.addressof(fold)
         _lib.check(self.lib.vgan_gemm_grouped_ex(arr, len(problems), ctypes.byref(x), self._stream()), "vgan_gemm_grouped_ex")
 
     def mse_grad(self, target, pred, gscale, part, g):

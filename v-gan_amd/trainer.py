@@ -291,14 +291,18 @@ class NoKLStepEngine:
             self.Dh, self.Dl = torch.zeros(rows_total, self.kp, **i16), torch.zeros(rows_total, self.kp, **i16)
             self.dsq = torch.zeros(rows_total, **f32)
             ops.gather_rows_split(data, None, self.center, None, self.dsq, True, self.Dh, self.Dl, n=rows_total)
-        if self.overlap or self.xx_ride:
+        # the X-X tiles riding in the M_4 launch instead (warm operand: the step's own Zh / Zl X half, identity row map)
+        self.xx_in_m4 = (self.bf3 and self.mode == "collapsed" and self.gram_tile == 64 and not self.overlap and not self.xx_ride and
+                         os.environ.get("VGAN_XX_IN_M4", "1") == "1")
+        self._xx_m4 = self._fold = None
+        if self.overlap or self.xx_ride or self.xx_in_m4:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
         else:
             self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile)
             self.n_main = self.tiles.shape[0]
         # the first-call bandwidth needs sum(L) over ALL pairs: computed by every rank from the full table (no collective)
         # (the calibration launch is the fp32 kernel: 64-wide tiles)
-        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not (self.overlap or self.xx_ride)) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
+        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not (self.overlap or self.xx_ride or self.xx_in_m4)) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
         self.partial = torch.zeros(max(self.tiles.shape[0], self.tiles_cal.shape[0]), 4, **f32)
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
@@ -442,7 +446,13 @@ class NoKLStepEngine:
         # M4[:d] = dlogits^T . [z|1]   (rows >= d stay zero: the homogeneous output coordinate carries no gradient)
         # (the library runs this long contraction on its tall-skinny 16-wave tiles; row slabs + a reduction launch, or
         # slab-summing staging loads in the consumers, were both measured slower)
-        ops.linear_backward_params(self.dlogits_pad, self.z_own, self.M[4][:self.dp], None)  # pad columns are zero: rows d.. of M_4 too
+        if self.xx_in_m4:
+            if self._xx_m4 is None:
+                ntx = self.tiles.shape[0] - self.n_main
+                self._xx_m4 = ops.xx_job(self.Zh, self.Zl, self.sqn, self.tiles[self.n_main:], self.bw, self.partial[self.n_main:self.n_main + ntx])
+            ops.linear_backward_params_xx(self.dlogits_pad, self.z_own, self.M[4][:self.dp], self._xx_m4)
+        else:
+            ops.linear_backward_params(self.dlogits_pad, self.z_own, self.M[4][:self.dp], None)  # pad columns are zero: rows d.. of M_4 too
         if dist:
             dist.all_reduce(self.M[4], group=self.group)  # (the side stream's prefetch may still be running beside it)
         # M_{k-1} = Wt_k^T M_k, i.e. M_3 = Wt_4^T M_4, M_2 = B_3^T M_4, M_1 = B_2^T M_4 (At_0 = I: Gt_1 IS M_1), and
@@ -453,7 +463,8 @@ class NoKLStepEngine:
         fused_noise = dict(next_noise=self.za, noise_cols=self.L, noise_ones_col=self.L, seed=self.seed,
                            step_counter=self.step_counter) if self.noise_mode == "device" else {}
         if not self.fuse_update:
-            ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])])
+            ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])],
+                             fold=self._fold if self.xx_in_m4 else None)
             ops.gemm_grouped([("NT", M[4], At[3], Gt[4]), ("NT", M[3], At[2], Gt[3]), ("NT", M[2], At[1], Gt[2])])
             ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
             return
@@ -463,7 +474,7 @@ class NoKLStepEngine:
         # launch.  Wt_1 is also an OPERAND of that launch (At_1 = Wt_1 in Gt_2 = M_2 . At_1^T), so the launch before it
         # snapshots it (a copy job riding there) and the product reads the snapshot.
         ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])],
-                         copy=(self.Wt[1], self.At1s))
+                         copy=(self.Wt[1], self.At1s), fold=self._fold if self.xx_in_m4 else None)
         w, off = self.widths, self.fp.offsets
         layers = [(self.Wt[k], off[2 * (k - 1)], off[2 * (k - 1) + 1], w[k], w[k - 1]) for k in (4, 3, 2, 1)]
         ops.gemm_grouped([("NT", M[4], At[3], Gt[4]), ("NT", M[3], At[2], Gt[3]), ("NT", M[2], self.At1s, Gt[2])],
@@ -535,9 +546,13 @@ class NoKLStepEngine:
         # workgroup: its outputs are first needed by the mask backward, so it leaves the critical path.  With several
         # ranks `stats` / `loss` are this rank's share (its tiles); the penalty is added by rank 0 only.
         if self._fin is None:
-            self._fin = ops.finalize_job(self.partial, self.tiles, self.colpart, ops.colmax_chunks(n), self.colkey, n, d,
-                                         self.pen if self.rank == 0 else 0.0, self.stats, self.loss, self.loss_accum, self.accum_scale,
-                                         self.step_counter)
+            fin_args = (self.partial, self.tiles, self.colpart, ops.colmax_chunks(n), self.colkey, n, d, self.pen if self.rank == 0 else 0.0,
+                        self.stats, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
+            if self.xx_in_m4:  # the X-X block sum arrives two launches later: the tail is split (include/vgan_hip.h)
+                self._fin = ops.finalize_job(*fin_args, mode=1, ntiles_main=self.n_main)
+                self._fold = ops.finalize_job(*fin_args, mode=2, ntiles_main=self.n_main)
+            else:
+                self._fin = ops.finalize_job(*fin_args)
         fin = self._fin
         if bf3:
             if self.rm_backward:
