@@ -114,11 +114,12 @@ def kernel_rooflines(eng):
     # the fp32 kernels work on 64-wide tiles: their own table when the engine runs the 128-wide bf16x3 Gram
     tiles64 = eng.tiles if eng.gram_tile == 64 else ops.build_tiles(n, 1, eng.rank, eng.world, device=eng.Z.device)
     part64 = torch.zeros(tiles64.shape[0], 4, device=eng.Z.device)
-    # the Gram launch as the step issues it: XY and YY tiles only when the X-X tiles run on the side stream (trainer.py); its
+    # the Gram launch as the step issues it: XY and YY tiles only when the X-X tiles run in another launch (trainer.py); its
     # algorithmic flop = the pairs it covers x 2 d: n^2 (XY) + n (n + 1) / 2 (YY upper triangle); row-sharded: 2 nl n
     pairs = (n * n + n * (n + 1) / 2) if eng.world == 1 else 2.0 * nl * n
-    main_flop = 2.0 * D_FEAT * pairs if eng.overlap else flop
-    if eng.gram_tile == 64 and eng.overlap:
+    split = eng.n_main < eng.tiles.shape[0]   # the X-X tiles run in another launch (trainer.py: the M_4 launch carries them)
+    main_flop = 2.0 * D_FEAT * pairs if split else flop
+    if eng.gram_tile == 64 and split:
         tiles64 = eng.tiles[:eng.n_main]
     ms = time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, tiles64, False, Wg, n + lo, part64))
     out["mmd_gram_kernel<4,false,1>"] = {"ms": ms, "tflops": (main_flop if eng.gram_tile == 64 else flop) / (ms * 1e-3) / 1e12,
@@ -128,17 +129,15 @@ def kernel_rooflines(eng):
     if eng.bf3:
         gs = nl * eng.dp
         gname = "mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"
-        # as the step launches it: the XY and YY tiles (the X-X tiles run in a side-stream launch of their own, see trainer.py);
-        # algorithmic flop of the pairs THIS launch covers: n^2 (XY) + n (n + 1) / 2 (YY upper triangle) pairs x 2 d
-        # (row-sharded: nl n + nl n pairs, no symmetry across ranks)
+        # as the step launches it (see above): the XY and YY tiles when the X-X tiles ride in the M_4 launch
         ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[:eng.n_main], eng.Wh, eng.Wl, n + lo, eng.partial,
                                                   tile=eng.gram_tile))
         out[gname] = {"ms": ms, "tflops": main_flop / (ms * 1e-3) / 1e12, "flop": main_flop, "tiles": int(eng.n_main)}
-        if eng.overlap and eng.tiles.shape[0] > eng.n_main:
+        if split:
             xx_flop = flop - main_flop
             ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[eng.n_main:], None, None, 0,
                                                       eng.partial[eng.n_main:], tile=eng.gram_tile))
-            out[gname + " [X-X tiles, side stream]"] = {"ms": ms, "tflops": xx_flop / (ms * 1e-3) / 1e12, "flop": xx_flop,
+            out[gname + " [X-X tiles alone]"] = {"ms": ms, "tflops": xx_flop / (ms * 1e-3) / 1e12, "flop": xx_flop,
                                                         "tiles": int(eng.tiles.shape[0] - eng.n_main)}
         big_bwd = ops.mmd_backward_bf3_tile(nl, d, eng.bsplits, eng.bwd_tile) == 128  # the library's own choice
         bname = "mmd_backward_bf3_big_kernel" if big_bwd else "mmd_backward_bf3_kernel<64>"

@@ -61,6 +61,7 @@ int vgan_linear_backward_params(const float* dy, int lddy, const float* x, int l
  * launch as surplus workgroups.  Shape contract: the 16-wave tall-skinny kernel's (out, in, leading dimensions % 4 == 0,
  * aligned bases, n >= 256, at most 32 64x64 output tiles). */
 struct vgan_xx_job;
+int vgan_linear_backward_params_xx_supported(int n, int in, int out); /* host-side query of that contract (1 / 0) */
 int vgan_linear_backward_params_xx(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int n, int in,
                                    int out, const struct vgan_xx_job* xx, vgan_stream_t stream);
 /* dst[i] = sum over s < nslabs of src[s*slab_stride + i], in ascending s (bitwise reproducible) */

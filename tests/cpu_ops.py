@@ -410,6 +410,9 @@ class CpuOps:
     def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
         return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))
 
+    def linear_backward_params_xx_supported(self, n, kin, out):
+        return bool(self.lib.vgan_linear_backward_params_xx_supported(int(n), int(kin), int(out)))
+
     def linear_backward_params_xx(self, dy, x, dW, xx):
         self.linear_backward_params(dy, x, dW, None)
         n = xx["Dh"].shape[0] // 2

@@ -229,6 +229,11 @@ extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const floa
     return VGAN_OK;
 }
 
+// host-side query: does (n, in, out) meet the shape contract of vgan_linear_backward_params_xx (alignment aside)?
+extern "C" int vgan_linear_backward_params_xx_supported(int n, int in, int out) {
+    return (n >= 256 && in > 0 && out > 0 && in % 4 == 0 && out % 4 == 0 && use_ks(out, in, n)) ? 1 : 0;
+}
+
 extern "C" int vgan_linear_backward_params_xx(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int n, int in,
                                               int out, const vgan_xx_job* xxjob, vgan_stream_t stream) {
     VGAN_CHECK_ARG(dy && x && dW && xxjob && n > 0 && in > 0 && out > 0 && lddy >= out && ldx >= in && lddw >= in);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vgan_linear_forward": (_i, [_p, _i, _i, _i64, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_input": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "vgan_linear_backward_params": (_i, [_p, _i, _p, _i, _i, _i64, _p, _i, _p, _i, _i, _i, _i, _i64, _p]),
+    "vgan_linear_backward_params_xx_supported": (_i, [_i, _i, _i]),
     "vgan_linear_backward_params_xx": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "vgan_reduce_slabs": (_i, [_p, _i64, _i, _p, _i64, _p]),
     "vgan_mask_project_forward": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _p, _p]),

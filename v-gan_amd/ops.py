@@ -89,6 +89,9 @@ class HipOps:
                                                         _ptr(dW), dW.stride(0), _ptr(db), n, kin, out, int(splits), int(slab_stride),
                                                         self._stream()), "vgan_linear_backward_params")
 
+    def linear_backward_params_xx_supported(self, n, kin, out):
+        return bool(self.lib.vgan_linear_backward_params_xx_supported(int(n), int(kin), int(out)))
+
     def linear_backward_params_xx(self, dy, x, dW, xx):
         """linear_backward_params (no bias, no slabs) with an xx_job() riding in the launch (the step's M_4 product)."""
         _mat(dy, "dy"), _mat(x, "x"), _mat(dW, "dW")

@@ -293,7 +293,7 @@ class NoKLStepEngine:
             ops.gather_rows_split(data, None, self.center, None, self.dsq, True, self.Dh, self.Dl, n=rows_total)
         # the X-X tiles riding in the M_4 launch instead (warm operand: the step's own Zh / Zl X half, identity row map)
         self.xx_in_m4 = (self.bf3 and self.mode == "collapsed" and self.gram_tile == 64 and not self.overlap and not self.xx_ride and
-                         os.environ.get("VGAN_XX_IN_M4", "1") == "1")
+                         ops.linear_backward_params_xx_supported(nl, self.e[0], dp) and os.environ.get("VGAN_XX_IN_M4", "1") == "1")
         self._xx_m4 = self._fold = None
         if self.overlap or self.xx_ride or self.xx_in_m4:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
