@@ -450,6 +450,7 @@ def test_vgan_kernel_learning_fit_matches_reference_run():
     g = load_golden("f4_kl_c1.npz")
     model = VGAN(batch_size=128, epochs=12)
     model.verbose = False
+    model.noise_source = "host"
     model.fit(g["data"])
     gl, dl = np.array(model.train_history["generator_loss"]), np.array(model.train_history["detector_loss"])
     assert np.isnan(gl[0]) and np.isnan(g["generator_loss"][0])          # no generator epoch yet (src/vgan.py:232-233)
@@ -1207,6 +1208,13 @@ def test_kl_step_engine_c3_size_vs_port(ops):
     np.testing.assert_allclose(float(eng.bw), float(tr.kernel.bandwidth), rtol=1e-5)
     for q, ref in zip(det.parameters(), tr.det):
         np.testing.assert_allclose(host(q), ref.detach().numpy(), rtol=0, atol=2e-5)
+
+
+def test_kl_resident_feed_equals_per_step_feed(ops):
+    """VGAN.fit's feed on the GPU: the epoch table walked by the device-side step counter inside the captured graphs gives,
+    bit for bit, the steps the per-step host feed gives; device noise + device shuffle reproduce themselves."""
+    from kl_cases import kl_resident_feed_equals_per_step_feed
+    kl_resident_feed_equals_per_step_feed(ops, torch.device("cuda"))
 
 
 @pytest.mark.parametrize("centred", [False, True])

@@ -7,6 +7,7 @@ import torch
 
 from conftest import load_golden
 from cpu_ops import CpuOps
+from kl_cases import kl_resident_feed_equals_per_step_feed
 from oracle import vgan_oracle as orc
 
 
@@ -288,6 +289,7 @@ def test_vgan_kl_fit_reproduces_reference_run_on_cpu_provider():
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
     g = load_golden("f4_kl_c1.npz")
     model = VGAN(batch_size=128, epochs=12)
+    model.noise_source = "host"
     model._ops_override = CpuOps()
     model.device = torch.device("cpu")
     model.verbose = False
@@ -302,4 +304,26 @@ def test_vgan_kl_fit_reproduces_reference_run_on_cpu_provider():
     for i, q in enumerate(model.detector.parameters()):
         np.testing.assert_allclose(q.detach().numpy(), g[f"detT_{i}"], rtol=0, atol=1e-3)
         assert bool(q.requires_grad) == bool(g[f"detT_rg_{i}"])
+    MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
+def test_kl_resident_feed_equals_per_step_feed_cpu_provider():
+    kl_resident_feed_equals_per_step_feed(CpuOps(), torch.device("cpu"))
+
+
+def test_vgan_kl_fit_device_feed_runs_on_cpu_provider():
+    """VGAN.fit with the noise and the shuffle both drawn on the device (the default noise source; shuffle_source="device"):
+    finite histories of the right length, the generator untouched, and the same run twice gives the same numbers."""
+    from src.vgan import VGAN
+    from src.models.Mmd_loss_constrained import MMDLossConstrained
+    hist = []
+    for _ in range(2):
+        MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+        model = VGAN(batch_size=64, epochs=7)
+        model._ops_override, model.device, model.verbose = CpuOps(), torch.device("cpu"), False
+        model.shuffle_source = "device"
+        model.fit(orc.synthetic_dataset("c1", rows=64 * 4 + 9))
+        hist.append((list(model.train_history["detector_loss"]), list(model.train_history["generator_loss"])))
+        assert len(hist[-1][0]) == 7 and np.isfinite(hist[-1][0]).all() and np.isfinite(hist[-1][1][1:]).all()
+    assert hist[0][0] == hist[1][0] and hist[0][1][1:] == hist[1][1][1:]
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None

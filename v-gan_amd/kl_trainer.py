@@ -90,11 +90,20 @@ class CollapsedChain:
 
 
 class KLStepEngine:
-    def __init__(self, ops, generator, detector, data, batch_size, lr_D, weight_decay, penalty_weight, use_graph=True):
+    def __init__(self, ops, generator, detector, data, batch_size, lr_D, weight_decay, penalty_weight, use_graph=True,
+                 batches_per_epoch=1, noise="host", seed=777):
+        """batches_per_epoch > 1: the resident feed of the no-kl engine -- the epoch's shuffled indices live in a device table
+        [batches_per_epoch, n] (set_epoch_batches / shuffle_epoch) and a device-side step counter, advanced by every step's
+        tail, picks the row, so a step needs no host copy.  noise = "device": the Philox draw keyed by (seed, step counter) is
+        the first launch of every step; "host": the caller provides it (set_noise, or the `noise` argument of a step)."""
         self.ops = ops
         # each step kind is captured into a HIP graph at its second use (the very first step calibrates the bandwidth
-        # eagerly); the batch indices and the noise are copied into fixed device buffers before every replay
+        # eagerly); nothing but the graph replay happens per step when the feed is resident
         self.use_graph = bool(use_graph) and data.is_cuda
+        assert noise in ("host", "device")
+        self.noise_mode = noise
+        self.seed = int(seed)
+        self.nb = int(batches_per_epoch)
         self.graphs = {}
         self.dev = data.device
         self.data = data
@@ -131,7 +140,8 @@ class KLStepEngine:
         self.logits = torch.zeros(n, d, **f32)
         self.S = torch.zeros(n, d, **f32)
         self.U = torch.zeros(n, d, **f32)
-        self.perm = torch.zeros(1, n, dtype=torch.int32, device=self.dev)
+        self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.sqxp = torch.zeros(2 * n, **f32)               # row norms of [batch ; U*batch] (a by-product nobody reads here)
         # detector on the 2n stacked rows, homogeneous layouts: XPh = [batch ; U*batch | 1], encH = [enc | 1], dec
         self.XPh = torch.zeros(2 * n, eE, **f32)
@@ -169,6 +179,18 @@ class KLStepEngine:
         self.bw.fill_(float(value))
         self.has_bw = True
 
+    def set_epoch_batches(self, idx):
+        """idx: [batches_per_epoch, n] integer tensor of shuffled row indices (DataLoader order)."""
+        self.perm.copy_(idx.to(dtype=torch.int32).view(self.nb, self.n), non_blocking=True)
+
+    def shuffle_epoch(self, epoch):
+        """This epoch's drop_last batches from the counter-based device permutation (vgan_shuffle_epoch): no host draw, no copy."""
+        self.ops.shuffle_epoch(self.perm, self.data.shape[0], self.seed, int(epoch))
+
+    def set_noise(self, z):
+        """Host-provided noise [n, L] for the next step (parity runs: the reference draws it on the CPU)."""
+        self.z.copy_(z.to(dtype=torch.float32), non_blocking=True)
+
     def epoch_sums(self):
         """(sum of MMD terms, sum of mse_X + mse_P) since the last call -- one host sync."""
         out = (float(self.acc_mmd.item()), float(self.acc_mse.item()))
@@ -178,8 +200,14 @@ class KLStepEngine:
 
     # ---- pieces -------------------------------------------------------------------------------------------
     def _feed(self, idx, noise):
-        self.perm.copy_(idx.to(dtype=torch.int32).view(1, self.n), non_blocking=True)
-        self.z.copy_(noise.to(dtype=torch.float32), non_blocking=True)
+        if idx is not None:
+            if self.nb != 1:
+                raise ValueError("per-step indices need batches_per_epoch == 1 (use set_epoch_batches / shuffle_epoch otherwise)")
+            self.set_epoch_batches(idx)
+        if noise is not None:
+            if self.noise_mode != "host":
+                raise ValueError("the engine draws its own noise (noise='device'); build it with noise='host' to provide it")
+            self.set_noise(noise)
 
     def _run(self, key, body):
         """Eager until the bandwidth exists, then one captured graph per step kind."""
@@ -197,15 +225,17 @@ class KLStepEngine:
 
     def _finalize_job(self, tiles):
         return self.ops.finalize_job(self.partial, tiles, self.colpart, self.ops.colmax_chunks(self.n), self.colkey, self.n, self.d,
-                                     self.pen, self.stats, self.mmd, self.acc_mmd, 1.0, None)
+                                     self.pen, self.stats, self.mmd, self.acc_mmd, 1.0, self.step_counter)
 
     def _forward(self, want_grad, want_decoder=True):
         """Returns True when the step tail (block sums -> loss) is still to be done by the caller (it rides in the MMD backward
         launch when there is one)."""
         ops, n, d, L = self.ops, self.n, self.d, self.L
+        if self.noise_mode == "device":
+            ops.noise_normal(self.zh, self.seed, self.step_counter, 0, cols=L, ones_col=L)
         self.G.forward(self.zh, self.logits)
         ops.mask_project_forward(self.logits, self.data, self.perm, self.S, self.U, self.XPh[:n], self.XPh[n:], self.sqxp[:n],
-                                 self.sqxp[n:])
+                                 self.sqxp[n:], row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
         self.E.forward(self.XPh, self.encH[:, :L])
         if want_decoder:
             self.D.forward(self.encH, self.dec[:, :d])
@@ -223,15 +253,15 @@ class KLStepEngine:
         if want_grad:
             return True
         ops.mmd_finalize(self.partial, tiles, self.colpart, ops.colmax_chunks(n), self.colkey, n, d, self.pen, self.stats, self.mmd,
-                         self.acc_mmd, 1.0, None)
+                         self.acc_mmd, 1.0, self.step_counter)
         return False
 
-    def generator_phase_step(self, idx, noise):
+    def generator_phase_step(self, idx=None, noise=None):
         """Loss evaluation of the generator phase: accumulates MMD(enc_X, enc_P, U) (src/vgan.py:295-329)."""
         self._feed(idx, noise)
         self._run("g", lambda: self._forward(want_grad=False, want_decoder=False))  # loss_G needs no decoder pass
 
-    def detector_step(self, idx, noise, train_encoder):
+    def detector_step(self, idx=None, noise=None, train_encoder=True):
         self._feed(idx, noise)
         self._run(("d", bool(train_encoder)), lambda: self._detector_body(bool(train_encoder)))
 

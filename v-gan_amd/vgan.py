@@ -360,6 +360,10 @@ class VGAN(_RunFolder):
         self.generator_optimizer = None
         self.device = _device()
         self.seed = 777  # the reference overrides the constructor's seed (src/vgan.py:48)
+        # build-specific knobs (not constructor arguments, so the reference signature is unchanged): as in VGAN_no_kl
+        self.noise_source = "device"   # "device": Philox on the GPU; "host": torch CPU generator (reference CPU-path RNG order)
+        self.shuffle_source = "host"   # "host": the DataLoader's own draws (reference RNG order); "device": vgan_shuffle_epoch
+        self.use_graph = True
         self.verbose = True
 
     def get_params(self):
@@ -408,7 +412,8 @@ class VGAN(_RunFolder):
         data = torch.as_tensor(X).to(device=device, dtype=torch.float32).contiguous()
         batch_number = train_size // self.batch_size
         engine = KLStepEngine(self._ops(), generator, detector, data, self.batch_size, self.lr_D, self.weight_decay,
-                              loss_function.weight)
+                              loss_function.weight, use_graph=self.use_graph, batches_per_epoch=batch_number,
+                              noise=self.noise_source, seed=self.seed)
         self._engine = engine
         if loss_function.kernel.bandwidth is not None:  # process-wide RBF already calibrated (reference quirk)
             engine.set_bandwidth(float(loss_function.kernel.bandwidth))
@@ -422,15 +427,25 @@ class VGAN(_RunFolder):
             loss_function.bandwidth = loss_function.kernel.bandwidth
             self.bandwidth = loss_function.bandwidth
 
+        def new_epoch_table(epoch):
+            # the epoch's shuffled drop_last batches become a device-resident table; the engine's step counter walks it
+            if self.shuffle_source == "device":
+                engine.shuffle_epoch(epoch)
+            else:
+                engine.set_epoch_batches(epoch_batches(train_size, self.batch_size))
+
         for epoch in range(self.epochs):
             if self.verbose:
                 print(f"\rEpoch {epoch} of {self.epochs}")
-            noise_tensor = torch.Tensor(self.batch_size, latent_size)
+            host_noise = self.noise_source == "host"
+            if host_noise:
+                noise_tensor = torch.Tensor(self.batch_size, latent_size)  # src/vgan.py:236
             if iternum_d <= self.iternum_d:
-                for idx in epoch_batches(train_size, self.batch_size):
-                    for p in detector.decoder.parameters():  # src/vgan.py:257-258
-                        p.requires_grad = True
-                    engine.detector_step(idx, noise_tensor.normal_(), train_encoder=encoder_trainable)
+                new_epoch_table(epoch)
+                for p in detector.decoder.parameters():  # src/vgan.py:257-258 (every step there; idempotent)
+                    p.requires_grad = True
+                for _ in range(batch_number):
+                    engine.detector_step(noise=noise_tensor.normal_() if host_noise else None, train_encoder=encoder_trainable)
                 mmd_sum, mse_sum = engine.epoch_sums()
                 # batch_loss_D = -(MMD - .1 mse(batch, batch_dec) - .1 mse(projected, projected_dec)), src/vgan.py:275-277
                 detector_loss = -(mmd_sum - 0.1 * mse_sum) / batch_number
@@ -443,11 +458,12 @@ class VGAN(_RunFolder):
                 # on the detached leaf.  ``batch_loss_G.backward()`` (:326) therefore never reaches the generator's parameters,
                 # ``gen_optimizer.step()`` (:327) sees no gradients and changes nothing: in VGAN.fit the generator keeps its
                 # N(0, 0.1) initialisation (fixture f4: genT == gen0 bit for bit) and this phase only evaluates the loss.
-                for idx in epoch_batches(train_size, self.batch_size):
-                    engine.generator_phase_step(idx, noise_tensor.normal_())
-                    for p in detector.parameters():  # src/vgan.py:319-320: freezes the detector for good
-                        p.requires_grad = False
-                    encoder_trainable = False
+                new_epoch_table(epoch)
+                for _ in range(batch_number):
+                    engine.generator_phase_step(noise=noise_tensor.normal_() if host_noise else None)
+                for p in detector.parameters():  # src/vgan.py:319-320 (every step there): freezes the detector for good
+                    p.requires_grad = False
+                encoder_trainable = False
                 generator_loss = engine.epoch_sums()[0] / batch_number
                 sync_bandwidth()
                 iternum_g += 1
