@@ -34,7 +34,22 @@ def host(t):
 
 
 # ------------------------------------------------------------------------------ Linear
-@pytest.mark.parametrize("n,kin,out", [(128, 1, 2), (100, 49, 98), (64, 20, 12), (1024, 392, 784), (130, 196, 392), (8, 4, 4)])
+def test_linear_backward_input_ragged_width_in_padded_rows(ops):
+    """dx = dy . W with a width that is no multiple of 4 (the decoder's input gradient: L = 49) when W's rows are padded to one:
+    the vector staging path reads the pad, stores only the true columns, and leaves the rest of dx alone."""
+    rng = np.random.default_rng(5)
+    n, kin, out = 2048, 49, 784
+    Wp = dev(rng.normal(size=(out, 52)) / np.sqrt(kin))        # columns 49..51: pad with arbitrary content
+    dy = dev(rng.normal(size=(n, out)))
+    dx = torch.full((n, 52), 7.0, device="cuda")
+    ops.linear_backward_input(dy, Wp[:, :kin], dx[:, :kin])
+    ref = host(dy).astype(np.float64) @ host(Wp[:, :kin]).astype(np.float64)
+    np.testing.assert_allclose(host(dx[:, :kin]), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    assert (host(dx[:, kin:]) == 7.0).all()
+
+
+@pytest.mark.parametrize("n,kin,out", [(128, 1, 2), (100, 49, 98), (64, 20, 12), (1024, 392, 784), (130, 196, 392), (8, 4, 4),
+                                       (2048, 788, 49), (300, 130, 33), (512, 256, 40)])  # the last three: narrow-output forward
 def test_linear_forward_backward(ops, n, kin, out):
     rng = np.random.default_rng(n + kin)
     x, W, b = rng.normal(size=(n, kin)), rng.normal(size=(out, kin)) / np.sqrt(kin), rng.normal(size=(out,))

@@ -89,15 +89,37 @@ __global__ __launch_bounds__(kBlock, 2) void linear_bwd_params_kernel(const floa
 
 // ---- tall-skinny variants (GemmTileKS): used when the 64x64 grid would be a handful of long-K tiles -----------------
 constexpr int KSBK = 128;
+// y = x . W^T + b for a narrow output (Encoder's collapsed chain: 2n x (d+1) -> L): 32x32 tiles, the K range of a tile split
+// over the NW waves of its workgroup -- 4x the workgroups of the 64x64 kernel, each with a 1/NW-long dependent MFMA chain
+template <int VEC, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_fwd_ks_kernel(const float* __restrict__ x, int ldx,
+                                                                               const float* __restrict__ W, int ldw,
+                                                                               const float* __restrict__ b, float* __restrict__ y,
+                                                                               int ldy, int n, int in, int out) {
+    using G = GemmTileKS<KSBK, KC, KC, VEC, NW>;
+    __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int col = n0 + G::col_of();
+    const float bias = (b != nullptr) ? b[min(col, out - 1)] : 0.f;
+    float o[G::NR];
+    G::run(x, ldx, W, ldw, m0, n0, n, out, in, lds, o);
+#pragma unroll
+    for (int rr = 0; rr < G::NR; ++rr) {
+        const int row = m0 + G::row_of(rr);
+        if (row < n && col < out) y[(long)row * ldy + col] = o[rr] + bias;
+    }
+}
+// `in_staged` >= in: the column range of W the staging may touch (a multiple of 4 on the vector path; the caller guarantees
+// ldw >= in_staged); columns >= in are computed and not stored
 template <int VEC>
 __global__ __launch_bounds__(kBlock, 2) void linear_bwd_input_ks_kernel(const float* __restrict__ dy, int lddy,
                                                                        const float* __restrict__ W, int ldw, float* __restrict__ dx,
-                                                                       int lddx, int n, int in, int out) {
+                                                                       int lddx, int n, int in, int out, int in_staged) {
     using G = GemmTileKS<KSBK, KC, MC, VEC>;
     __shared__ __attribute__((aligned(16))) float lds[G::kLdsFloats];
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     float o[G::NR];
-    G::run(dy, lddy, W, ldw, m0, n0, n, in, out, lds, o);
+    G::run(dy, lddy, W, ldw, m0, n0, n, in_staged, out, lds, o);
     const int col = n0 + G::col_of();
 #pragma unroll
     for (int rr = 0; rr < G::NR; ++rr) {
@@ -167,6 +189,17 @@ extern "C" int vgan_linear_forward(const float* x, int ldx, int x_nslabs, int64_
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (in % 4 == 0) && (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(x) && aligned16(W) && (x_slab_stride % 4 == 0);
     const long xs = (long)x_slab_stride;
+    if (x_nslabs == 1 && use_ks(n, out, in)) {  // narrow output, long contraction
+        dim3 g((out + 31) / 32, (n + 31) / 32);
+        if (vec && in >= 512)
+            hipLaunchKernelGGL((linear_fwd_ks_kernel<4, 16>), g, dim3(1024), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out);
+        else if (vec)
+            hipLaunchKernelGGL((linear_fwd_ks_kernel<4, 4>), g, dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out);
+        else
+            hipLaunchKernelGGL((linear_fwd_ks_kernel<1, 4>), g, dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out);
+        VGAN_CHECK_LAUNCH();
+        return VGAN_OK;
+    }
 #define VGAN_FWD(V, S) hipLaunchKernelGGL((linear_fwd_kernel<V, S>), grid_for(n, out), dim3(kBlock), 0, s, x, ldx, W, ldw, b, y, ldy, n, in, out, x_nslabs, xs)
     if (x_nslabs > 1) { if (vec) VGAN_FWD(4, true); else VGAN_FWD(1, true); }
     else { if (vec) VGAN_FWD(4, false); else VGAN_FWD(1, false); }
@@ -179,13 +212,15 @@ extern "C" int vgan_linear_backward_input(const float* dy, int lddy, const float
                                           int out, vgan_stream_t stream) {
     VGAN_CHECK_ARG(dy && W && dx && n > 0 && in > 0 && out > 0 && lddy >= out && ldw >= in && lddx >= in);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = (out % 4 == 0) && (lddy % 4 == 0) && (in % 4 == 0) && (ldw % 4 == 0) && aligned16(dy) && aligned16(W);
+    const bool vec_but_in = (out % 4 == 0) && (lddy % 4 == 0) && (ldw % 4 == 0) && aligned16(dy) && aligned16(W);
+    const bool vec = vec_but_in && (in % 4 == 0);
     if (use_ks(n, in, out)) {
         dim3 g((in + 31) / 32, (n + 31) / 32);
-        if (vec)
-            hipLaunchKernelGGL(linear_bwd_input_ks_kernel<4>, g, dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
+        const int in4 = (in + 3) / 4 * 4;  // W's rows are ldw long: a ragged last group of 4 columns is still inside the row
+        if (vec_but_in && ldw >= in4)
+            hipLaunchKernelGGL(linear_bwd_input_ks_kernel<4>, g, dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out, in4);
         else
-            hipLaunchKernelGGL(linear_bwd_input_ks_kernel<1>, g, dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
+            hipLaunchKernelGGL(linear_bwd_input_ks_kernel<1>, g, dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out, in);
     } else if (vec)
         hipLaunchKernelGGL(linear_bwd_input_kernel<4>, grid_for(n, in), dim3(kBlock), 0, s, dy, lddy, W, ldw, dx, lddx, n, in, out);
     else
