@@ -1,0 +1,123 @@
+// Prototype of the 64x64 split-bf16 tile main loop with direct-to-LDS staging (global_load_lds_dwordx4), checked against
+// GemmBF3<64>::run on the same operands (tools only, not part of the library).  256 threads, two workgroups per CU.
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include "../v-gan_amd/csrc/gemm_bf3.hpp"
+using namespace vgan;
+namespace vgan { void set_error(const char*, ...) {} }
+
+struct G64 {
+    static constexpr int BK = 64, PART = 64 * 128, BUF = 4 * PART, kLdsBytes = 2 * BUF;  // 65,536 B: two workgroups per CU
+    typedef char __attribute__((address_space(3))) lds_c;
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K, char* lds_generic,
+                                               f32x16& acc) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        const int fi = lane & 31, fh = lane >> 5;
+        // wave w fills part w (Ah, Al, Bh, Bl): 64 rows = 8 pieces of 8 rows x 128 B; lane's chunk (lane & 7) ^ swz(row)
+        const unsigned short* base = wave == 0 ? Ah : wave == 1 ? Al : wave == 2 ? Bh : Bl;
+        const long ld = wave < 2 ? lda : ldb;
+        const int r0g = wave < 2 ? m0 : n0, lim = wave < 2 ? M : N;
+        const char* src[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = 8 * e + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            src[e] = reinterpret_cast<const char*>(base + (long)min(r0g + row, lim - 1) * ld) + 16 * c;
+        }
+        auto fill = [&](int kt) {
+            lds_c* d = lds + (kt & 1) * BUF + wave * PART;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src[e] + 2 * (long)kt * BK),
+                                                 (void __attribute__((address_space(3)))*)(d + e * 1024), 16, 0, 0);
+        };
+        const int nk = K / BK;
+        fill(0);
+        __syncthreads();
+        const int sw = (fi >> 1) & 7;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) fill(kt + 1);
+            const lds_c* buf = lds + (kt & 1) * BUF;
+            const lds_c* pa = buf + (wm0 + fi) * 128;
+            const lds_c* pb = buf + 2 * PART + (wn0 + fi) * 128;
+            u32x4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int pos = ((2 * s + fh) ^ sw) << 4;
+                ah[s] = *(const lds_u4*)(pa + pos);
+                al[s] = *(const lds_u4*)(pa + PART + pos);
+                bh[s] = *(const lds_u4*)(pb + pos);
+                bl[s] = *(const lds_u4*)(pb + PART + pos);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[s]), xl = __builtin_bit_cast(bf16x8, al[s]);
+                const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[s]), yl = __builtin_bit_cast(bf16x8, bl[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+};
+struct B64 {
+    static constexpr int kLdsBytes = GemmBF3<64>::kLdsBytes;
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K, char* lds, f32x16& acc) {
+        GemmBF3<64>::run<false>(Ah, Al, lda, Bh, Bl, ldb, m0, n0, M, N, K, lds, nullptr, acc);
+    }
+};
+template <class G>
+__global__ __launch_bounds__(256, 2) void k(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out) {
+    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
+    const int r0 = (blockIdx.x / tiles_per_row) * 64, c0 = (blockIdx.x % tiles_per_row) * 64;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    G::run(Zh, Zl, kp, Zh, Zl, kp, r0, c0, N, N, kp, lds, acc);
+    for (int r = 0; r < 16; ++r) out[((size_t)blockIdx.x * 16 + r) * 256 + threadIdx.x] = acc[r];
+}
+template <class G>
+static void bench(const char* name, const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int ntiles, float* out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int tpr = N / 64;
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k<G>, dim3(ntiles), dim3(256), 0, 0, Zh, Zl, kp, N, tpr, out);
+    hipEventRecord(e0);
+    const int it = 50;
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(k<G>, dim3(ntiles), dim3(256), 0, 0, Zh, Zl, kp, N, tpr, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-6s tiles=%d: %.1f us/launch, %.1f algorithmic TFLOP/s\n", name, ntiles, ms / it * 1e3, 2.0 * 64 * 64 * kp * ntiles / (ms / it * 1e-3) / 1e12);
+}
+int main() {
+    const int N = 2048, kp = 832;
+    unsigned short *Zh, *Zl;
+    float *o1, *o2;
+    hipMalloc(&Zh, (size_t)N * kp * 2);
+    hipMalloc(&Zl, (size_t)N * kp * 2);
+    const size_t no = (size_t)528 * 16 * 256;
+    hipMalloc(&o1, no * 4);
+    hipMalloc(&o2, no * 4);
+    std::vector<unsigned short> h((size_t)N * kp);
+    for (auto& v : h) v = 0x3F00 + rand() % 128 + ((rand() & 1) << 15);
+    hipMemcpy(Zh, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    for (auto& v : h) v = 0x3B00 + rand() % 128;
+    hipMemcpy(Zl, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    for (int nt : {256, 392, 512, 528}) {
+        bench<B64>("base", Zh, Zl, kp, N, nt, o1);
+        bench<G64>("glds", Zh, Zl, kp, N, nt, o2);
+    }
+    std::vector<float> a(no), b(no);
+    hipMemcpy(a.data(), o1, no * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(b.data(), o2, no * 4, hipMemcpyDeviceToHost);
+    double md = 0, mx = 0;
+    for (size_t i = 0; i < no; ++i) { md = fmax(md, fabs((double)a[i] - b[i])); mx = fmax(mx, fabs((double)a[i])); }
+    printf("max |base - glds| = %.3g (max |value| %.3g)\n", md, mx);
+    return 0;
+}

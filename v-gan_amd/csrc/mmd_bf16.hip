@@ -188,7 +188,9 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
                                                                   unsigned short* __restrict__ Wl, int ldw, int wrow0,
                                                                   float* __restrict__ partial, ColmaxJob cj) {
     using G = GemmBF3Big;
-    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
+    constexpr int LDT = 136, LDM = 129;  // epilogue images Wt[i][j]: b128 reads, 4*LDT = 32 mod 64 banks; WtT[j][i]: scalar, odd stride
+    constexpr int kEpiBytes = (128 * LDT + 128 * LDM) * 4;
+    __shared__ __attribute__((aligned(16))) char lds[kEpiBytes > G::kLdsBytes ? kEpiBytes : G::kLdsBytes];
     __shared__ float red[8];
     if ((int)blockIdx.x >= ntiles) {
         const int cb = blockIdx.x - ntiles;
@@ -220,10 +222,8 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
     const bool store = (td.flags & VGAN_TF_STORE) && Wh != nullptr;
     const bool mirror = store && (td.flags & VGAN_TF_MIRROR);
     float ksum = 0.f;
-    constexpr int LDT = 136, LDM = 129;  // Wt[i][j]: b128 reads, 4*LDT = 32 mod 64 banks; WtT[j][i]: scalar, odd stride
     lds_f* Wt = (lds_f*)(float*)lds;
     lds_f* WtT = Wt + 128 * LDT;
-    static_assert((128 * LDT + 128 * LDM) * 4 <= G::kLdsBytes, "epilogue images must fit the staging buffers");
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -382,18 +382,10 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
     const int m0 = (band * 4 + rem % rows_in_band) * 128, n0 = (rem / rows_in_band) * 128;
     const int k0 = blockIdx.y * kchunk, klen = min(kchunk, kn - k0);
     out += blockIdx.y * slab_stride;
-    // epilogue operands requested before the main loop
+    // (the epilogue's operands are requested AFTER the main loop here: its K loop is long -- these tiles run from c4 sizes up --
+    //  and the 64 registers the early request holds across it spill)
     const int col = n0 + G::sub_col(), colc = min(col, p - 1);
-    float z_pre[2][16], m_pre[2][16];
     const float mshift = mul_shift != nullptr ? mul_shift[colc] : 0.f;
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowc = min(m0 + G::sub_row(i2, r), nr - 1);
-            z_pre[i2][r] = Z[(long)(wrow0 + rowc) * ldz + colc];
-            m_pre[i2][r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] + mshift : 1.f;
-        }
     f32x16 acc[2];
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
@@ -408,15 +400,23 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
     }
     if (col >= p) return;
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
+    for (int i2 = 0; i2 < 2; ++i2) {
+        float z_pre[16], m_pre[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = min(m0 + G::sub_row(i2, r), nr - 1);
+            z_pre[r] = Z[(long)(wrow0 + rowc) * ldz + colc];
+            m_pre[r] = mul != nullptr ? mul[(long)rowc * ldmul + colc] + mshift : 1.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lrow = G::sub_row(i2, r), row = m0 + lrow;
             if (row < nr) {
-                const float v = klen > 0 ? 2.f * (rs[lrow] * z_pre[i2][r] - acc[i2][r]) : 0.f;
-                out[(long)row * ldo + col] = v * m_pre[i2][r];
+                const float v = klen > 0 ? 2.f * (rs[lrow] * z_pre[r] - acc[i2][r]) : 0.f;
+                out[(long)row * ldo + col] = v * m_pre[r];
             }
         }
+    }
 }
 
 }  // namespace vgan
