@@ -113,6 +113,47 @@ def test_mask_project_forward_golden(ops, name):
     np.testing.assert_allclose(host(dl), ref, rtol=0, atol=5e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n,d", [(72, 2048), (40, 4096), (24, 1500), (16, 4100)])
+def test_mask_project_forward_backward_wide_rows(ops, n, d):
+    """The row-in-registers mask kernels beyond d = 1024 (8 and 16 float4 per lane: c4 / c5 widths), a width that is no
+    multiple of 256, and one past 4096 (generic kernels) against the float64 oracle: softmax values, mask decisions away from the
+    threshold, the projected rows, both row norms, the slab-summing backward with the penalty keys."""
+    rng = np.random.default_rng(n + d)
+    logits = (rng.normal(size=(n, d)) * 2.0).astype(np.float32)
+    X = rng.normal(size=(3 * n, d)).astype(np.float32)
+    perm = rng.permutation(3 * n)[:n].astype(np.int32)
+    center = X.mean(0).astype(np.float32)
+    S, U = torch.empty(n, d, device="cuda"), torch.empty(n, d, device="cuda")
+    Z = torch.zeros(2 * n, d, device="cuda")
+    sq = torch.empty(2 * n, device="cuda")
+    ops.mask_project_forward(dev(logits), dev(X), dev(perm, torch.int32), S, U, Z[:n], Z[n:], sq[:n], sq[n:], center=dev(center))
+    Ur, sr = orc.upper_softmax_forward(logits.astype(np.float64))
+    np.testing.assert_allclose(host(S), sr, rtol=2e-5, atol=1e-12)
+    clear = np.abs(sr * d - 1.0) > 1e-4                       # decisions within fp32 rounding of the threshold may flip
+    assert np.array_equal((host(U) == 1)[clear], (Ur == 1)[clear])
+    Xb = X[perm].astype(np.float64)
+    np.testing.assert_allclose(host(Z[:n]), Xb - center, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(host(Z[n:]), host(U).astype(np.float64) * Xb - center, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(host(sq), (host(Z).astype(np.float64) ** 2).sum(1), rtol=1e-5)
+    # backward: two slabs of upstream gradient, penalty keys pointing at rows of this batch
+    g0, g1 = rng.normal(size=(n, d)).astype(np.float32), rng.normal(size=(n, d)).astype(np.float32)
+    slabs = dev(np.stack([g0, g1]))
+    arg = rng.integers(0, n, size=d)
+    colkey = dev(((np.uint64(1) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - arg.astype(np.uint64))).astype(np.uint64).view(np.int64), torch.int64)
+    dl = torch.empty(n, d, device="cuda")
+    ops.mask_backward(slabs[0], S, colkey, 10.0, 0, dl, nslabs=2, slab_stride=n * d)
+    want = CpuOps_mask_backward(g0.astype(np.float64) + g1, host(S).astype(np.float64), arg, 10.0, d)
+    np.testing.assert_allclose(host(dl), want, rtol=0, atol=5e-5 * np.abs(want).max())
+
+
+def CpuOps_mask_backward(g, s, arg, pen_weight, d):
+    """float64 restatement of the mask backward with the penalty gradient -w/d at the column arg-max rows
+    (Mmd_loss_constrained.py:46-50 through Generator.py:19-21)."""
+    g = g.copy()
+    g[arg, np.arange(d)] += -pen_weight / d
+    return orc.upper_softmax_backward(g, s)
+
+
 # ------------------------------------------------------------------------------ MMD
 def run_mmd(ops, X, Y, U, weight, bw=None, grad_mode=1):
     n, p = X.shape

@@ -177,6 +177,14 @@ static inline bool use_ks(int rows, int cols, int k) {
     return tiles64 <= 32 && k >= 128;
 }
 
+// the weight-gradient product dW = dy^T x has the batch as its contraction: from c4 sizes up a narrow dW (the collapsed
+// generator's M_4: 2048 x 132 over 4096 rows) is ~100 64x64 tiles with a very long K loop each -- the 16-wave tall-skinny tile
+// (4x the workgroups, K split over 16 waves) again, although the 64x64 grid is no longer "a handful"
+static inline bool use_ks_params(int rows, int cols, int k) {
+    const long tiles64 = (long)((rows + 63) / 64) * ((cols + 63) / 64);
+    return use_ks(rows, cols, k) || (tiles64 <= 192 && k >= 2048);
+}
+
 static inline dim3 grid_for(int rows, int cols) { return dim3((cols + LBN - 1) / LBN, (rows + LBM - 1) / LBM, 1); }
 
 }  // namespace vgan
@@ -245,7 +253,7 @@ extern "C" int vgan_linear_backward_params(const float* dy, int lddy, const floa
     grid.z = splits;  // slices beyond nz see klen <= 0 and write zeros, so the reducer may always sum `splits` slabs
     (void)nz;
     const long xs = (long)x_slab_stride;
-    if (splits == 1 && x_nslabs == 1 && db == nullptr && use_ks(out, in, n)) {  // tall-skinny: no slabs needed at all
+    if (splits == 1 && x_nslabs == 1 && db == nullptr && use_ks_params(out, in, n)) {  // tall-skinny: no slabs needed at all
         dim3 g((in + 31) / 32, (out + 31) / 32);
         if (vec && n >= 256)  // long contraction: 16 waves per workgroup (see GemmTileKS)
             hipLaunchKernelGGL((linear_bwd_params_ks_kernel<4, 16>), g, dim3(1024), 0, s, dy, lddy, x, ldx, dW, lddw, n, in, out);

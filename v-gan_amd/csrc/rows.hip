@@ -557,7 +557,9 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
     const RowSel sel{rows, reinterpret_cast<const unsigned long long*>(row_cursor), row_batches, row_stride, row_offset};
     const dim3 grid((n + kRowsPerBlock - 1) / kRowsPerBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (d % 4 == 0) && (d <= 1024) && (ldl % 4 == 0) && (ldd % 4 == 0) && (ldz % 4 == 0) && aligned16(logits) &&
+    // row-in-registers path: one wave per row, d / 256 float4 per lane and array -- up to d = 4096 (16 per lane); the in-launch
+    // logits (chain) stage At_4 through LDS and stop at d = 1024
+    const bool vec = (d % 4 == 0) && (d <= (chain != nullptr ? 1024 : 4096)) && (ldl % 4 == 0) && (ldd % 4 == 0) && (ldz % 4 == 0) && aligned16(logits) &&
                      aligned16(data) && aligned16(S) && (U == nullptr || aligned16(U)) && (Zx == nullptr || aligned16(Zx)) && aligned16(Zy) && (center == nullptr || aligned16(center));
     if (vec) {
         const int nt = (d / 4 + 63) / 64;
@@ -574,7 +576,13 @@ extern "C" int vgan_mask_project_forward(const float* logits, int ldl, const flo
             hipLaunchKernelGGL((mask_forward_vec_kernel<NT, false>), grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, \
                                sqy, n, d, center, norm_split, ch);                                                                        \
     } while (0)
-        if (nt == 1) VGAN_LAUNCH_FWD(1); else if (nt == 2) VGAN_LAUNCH_FWD(2); else if (nt == 3) VGAN_LAUNCH_FWD(3); else VGAN_LAUNCH_FWD(4);
+        if (nt == 1) VGAN_LAUNCH_FWD(1); else if (nt == 2) VGAN_LAUNCH_FWD(2); else if (nt == 3) VGAN_LAUNCH_FWD(3); else if (nt == 4) VGAN_LAUNCH_FWD(4);
+        else if (nt <= 8)
+            hipLaunchKernelGGL((mask_forward_vec_kernel<8, false>), grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d,
+                               center, norm_split, ch);
+        else
+            hipLaunchKernelGGL((mask_forward_vec_kernel<16, false>), grid, block, 0, st, logits, ldl, data, ldd, sel, S, U, Zx, Zy, ldz, sqx, sqy, n, d,
+                               center, norm_split, ch);
 #undef VGAN_LAUNCH_FWD
     } else {
         VGAN_CHECK_ARG(chain == nullptr);  // the in-launch logits need the row-in-registers path (d % 4 == 0, d <= 1024, aligned)
@@ -661,12 +669,13 @@ extern "C" int vgan_mask_backward(const float* gU, int ldg, int nslabs, int64_t 
     const dim3 grid((n + kRowsPerBlock - 1) / kRowsPerBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     const unsigned long long* ck = reinterpret_cast<const unsigned long long*>(colkey);
-    const bool vec = (d % 4 == 0) && (d <= 1024) && (ldg % 4 == 0) && (lds % 4 == 0) && (ldo % 4 == 0) && (slab_stride % 4 == 0) &&
+    const bool vec = (d % 4 == 0) && (d <= 4096) && (ldg % 4 == 0) && (lds % 4 == 0) && (ldo % 4 == 0) && (slab_stride % 4 == 0) &&
                      aligned16(gU) && aligned16(S) && aligned16(dlogits) && (colkey == nullptr || aligned16(colkey));
     if (vec) {
         const int nt = (d / 4 + 63) / 64;
 #define VGAN_LAUNCH_BWD(NT) hipLaunchKernelGGL(mask_backward_vec_kernel<NT>, grid, block, 0, st, gU, ldg, S, lds, ck, pen_weight, row_offset, dlogits, ldo, n, d, nslabs, (long)slab_stride)
-        if (nt == 1) VGAN_LAUNCH_BWD(1); else if (nt == 2) VGAN_LAUNCH_BWD(2); else if (nt == 3) VGAN_LAUNCH_BWD(3); else VGAN_LAUNCH_BWD(4);
+        if (nt == 1) VGAN_LAUNCH_BWD(1); else if (nt == 2) VGAN_LAUNCH_BWD(2); else if (nt == 3) VGAN_LAUNCH_BWD(3); else if (nt == 4) VGAN_LAUNCH_BWD(4);
+        else if (nt <= 8) VGAN_LAUNCH_BWD(8); else VGAN_LAUNCH_BWD(16);
 #undef VGAN_LAUNCH_BWD
     } else
         hipLaunchKernelGGL(mask_backward_kernel, grid, block, 0, st, gU, ldg, S, lds, ck, pen_weight, row_offset, dlogits, ldo, n, d, nslabs,
