@@ -178,11 +178,12 @@ static inline bool use_ks(int rows, int cols, int k) {
 }
 
 // the weight-gradient product dW = dy^T x has the batch as its contraction: from c4 sizes up a narrow dW (the collapsed
-// generator's M_4: 2048 x 132 over 4096 rows) is ~100 64x64 tiles with a very long K loop each -- the 16-wave tall-skinny tile
-// (4x the workgroups, K split over 16 waves) again, although the 64x64 grid is no longer "a handful"
+// generator's M_4: 2048 x 132 over 4096 rows, 4096 x 260 over 8192) is 100-320 64x64 tiles with a very long K loop each -- the
+// 16-wave tall-skinny tile (4x the workgroups, K split over 16 waves) again, although the 64x64 grid is no longer "a handful":
+// measured 130 -> 49 us at c4, 332 -> 244 us at c5
 static inline bool use_ks_params(int rows, int cols, int k) {
     const long tiles64 = (long)((rows + 63) / 64) * ((cols + 63) / 64);
-    return use_ks(rows, cols, k) || (tiles64 <= 192 && k >= 2048);
+    return use_ks(rows, cols, k) || (tiles64 <= 512 && k >= 2048);
 }
 
 static inline dim3 grid_for(int rows, int cols) { return dim3((cols + LBN - 1) / LBN, (rows + LBM - 1) / LBM, 1); }
