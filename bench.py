@@ -79,11 +79,16 @@ def build_engine(rank, world, use_graph, **engine_kw):
 
 
 def run_steps(eng, count, start_step):
+    """`count` steps from global step index `start_step`, epoch by epoch as fit() runs them: a new shuffled table at every
+    epoch start, then the epoch's steps through the engine's run_steps (blocks of steps per graph launch)."""
     from vgan_amd.vgan import epoch_batches
-    for t in range(start_step, start_step + count):
+    t, end = start_step, start_step + count
+    while t < end:
         if t % EPOCH_BATCHES == 0:  # new shuffled epoch, as fit() does
             eng.set_epoch_batches(epoch_batches(eng.data.shape[0], N_BATCH))
-        eng.step()
+        k = min(end - t, EPOCH_BATCHES - t % EPOCH_BATCHES)
+        eng.run_steps(k)
+        t += k
 
 
 def time_kernel(fn, iters=30):
@@ -236,19 +241,22 @@ def bench_kl(args):
     idx = table[0]
     z = torch.randn(N_BATCH, L)
     steps = min(args.steps, 1000)
-    kinds = {"detector_step_trainable_encoder": lambda: eng.detector_step(train_encoder=True),
-             "detector_step_frozen_encoder": lambda: eng.detector_step(train_encoder=False),
-             "generator_phase_step": lambda: eng.generator_phase_step()}
+    # an epoch of a step kind per call, as VGAN.fit issues them (blocks of steps per graph launch)
+    kinds = {"detector_step_trainable_encoder": lambda: eng.detector_step(train_encoder=True, count=nb),
+             "detector_step_frozen_encoder": lambda: eng.detector_step(train_encoder=False, count=nb),
+             "generator_phase_step": lambda: eng.generator_phase_step(count=nb)}
     res = {}
+    epochs = max(1, steps // nb)
     for name, fn in kinds.items():
-        for _ in range(30):
+        for _ in range(3):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(epochs):
             fn()
         torch.cuda.synchronize()
-        res[name] = (time.perf_counter() - t0) / steps
+        res[name] = (time.perf_counter() - t0) / (epochs * nb)
+    steps = epochs * nb
     mix = (res["detector_step_frozen_encoder"] + 5.0 * res["generator_phase_step"]) / 6.0
     # the MMD of this path runs at p = L (exp-bound regime): algorithmic 8 n^2 L flop and 2 n^2 exps per step
     n, p = N_BATCH, eng.pz

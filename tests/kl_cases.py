@@ -66,3 +66,13 @@ def kl_resident_feed_equals_per_step_feed(ops, device):
             sums.append(c.epoch_sums())
         out.append(sums)
     assert out[0] == out[1] and all(np.isfinite(v) for s in out[0] for v in s)
+    # ... and an epoch issued as ONE call (blocks of steps per graph launch on the GPU) equals the same epoch step by step
+    c, det_c = _kl_engine(ops, device, nb, "device", rows)
+    sums = []
+    for epoch in range(2):
+        c.shuffle_epoch(epoch)
+        c.detector_step(train_encoder=True, count=nb) if epoch == 0 else c.generator_phase_step(count=nb)
+        sums.append(c.epoch_sums())
+    assert sums == out[0] and int(c.step_counter.item()) == 2 * nb
+    with pytest.raises(ValueError):
+        c.generator_phase_step(noise=z, count=2)

@@ -598,6 +598,36 @@ def test_two_fits_in_one_process_share_the_bandwidth():
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
 
 
+@pytest.mark.parametrize("n,d,nb,precision", [(128, 20, 5, "fp32"), (1024, 784, 16, "bf16x3"), (256, 100, 20, "fp32")])
+def test_run_steps_blocks_equal_single_steps(ops, n, d, nb, precision):
+    """NoKLStepEngine.run_steps (blocks of steps replayed from ONE graph launch; the device-side step counter picks the batch
+    and keys the noise) against the same steps launched one graph at a time: epoch losses, bandwidth and all eight parameter
+    tensors bit for bit over three epochs, including an epoch length that is no multiple of the block (nb = 20, block 16)."""
+    rng = np.random.default_rng(n + d)
+    data = rng.normal(size=(nb * n + 7, d)).astype(np.float32)
+    params = orc.synthetic_generator_params(d, seed=3)
+    runs = []
+    for blocks in (True, False):
+        eng, gen = make_engine(ops, params, data, n, nb=nb, graph=True, noise="device", mmd_precision=precision)
+        losses = []
+        for epoch in range(3):
+            eng.shuffle_epoch(epoch)
+            if blocks:
+                eng.run_steps(nb)
+            else:
+                for _ in range(nb):
+                    eng.step()
+            losses.append(eng.epoch_loss())
+        assert eng.steps_done == 3 * nb and int(eng.step_counter.item()) == 3 * nb
+        if blocks:
+            assert eng.graph_multi is not None and eng.steps_per_graph == min(16, nb)
+        runs.append((losses, float(eng.bw.item()), [host(q).copy() for q in gen.parameters()]))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert all(np.isfinite(runs[0][0]))
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert np.array_equal(a, b)
+
+
 def test_device_shuffle_and_mask_unique(ops):
     """SURVEY 8f rank 4 on the device: vgan_shuffle_epoch equals the host evaluation of the same counter-based permutation
     (a bijection: distinct rows, different every epoch) and a fit driven by it trains; vgan_mask_unique equals

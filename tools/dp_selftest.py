@@ -36,7 +36,8 @@ for graph in (() if only else (False, True)):
 import time
 if world == 1:
     for G in ((int(only),) if only else (1, 2, 4, 8)):
-        for schedule in (False, "serial", True):  # plain | overlapped schedule on one stream | overlapped on a side stream
+        plain_only = os.environ.get("VGAN_SELFTEST_PLAIN") == "1"  # profiling aid: the default schedule only
+        for schedule in ((False,) if plain_only else (False, "serial", True)):  # plain | overlapped schedule on one stream | on a side stream
             eng, data, params = bench.build_engine(0, G, True, force_exchange=True, overlap_exchange=schedule)
             bench.run_steps(eng, 64, 0)
             torch.cuda.synchronize()

@@ -321,10 +321,12 @@ class VGAN_no_kl(_RunFolder):
                 engine.set_epoch_batches(epoch_batches(train_size, self.batch_size))
             if self.noise_source == "host":
                 noise_tensor = torch.Tensor(self.batch_size, latent_size)  # src/vgan.py:594
-            for _ in range(batches_per_epoch):
-                if self.noise_source == "host":
+            if self.noise_source == "host":
+                for _ in range(batches_per_epoch):
                     engine.set_noise(noise_tensor.normal_())  # src/vgan.py:610
-                engine.step()
+                    engine.step()
+            else:
+                engine.run_steps(batches_per_epoch)  # blocks of steps per graph launch (NoKLStepEngine.run_steps)
             generator_loss = engine.epoch_loss()  # the only host sync of the epoch
             if loss_function.kernel.bandwidth is None:
                 loss_function.kernel.bandwidth = engine.bw.view(())
@@ -444,8 +446,11 @@ class VGAN(_RunFolder):
                 new_epoch_table(epoch)
                 for p in detector.decoder.parameters():  # src/vgan.py:257-258 (every step there; idempotent)
                     p.requires_grad = True
-                for _ in range(batch_number):
-                    engine.detector_step(noise=noise_tensor.normal_() if host_noise else None, train_encoder=encoder_trainable)
+                if host_noise:
+                    for _ in range(batch_number):
+                        engine.detector_step(noise=noise_tensor.normal_(), train_encoder=encoder_trainable)
+                else:
+                    engine.detector_step(train_encoder=encoder_trainable, count=batch_number)
                 mmd_sum, mse_sum = engine.epoch_sums()
                 # batch_loss_D = -(MMD - .1 mse(batch, batch_dec) - .1 mse(projected, projected_dec)), src/vgan.py:275-277
                 detector_loss = -(mmd_sum - 0.1 * mse_sum) / batch_number
@@ -459,8 +464,11 @@ class VGAN(_RunFolder):
                 # ``gen_optimizer.step()`` (:327) sees no gradients and changes nothing: in VGAN.fit the generator keeps its
                 # N(0, 0.1) initialisation (fixture f4: genT == gen0 bit for bit) and this phase only evaluates the loss.
                 new_epoch_table(epoch)
-                for _ in range(batch_number):
-                    engine.generator_phase_step(noise=noise_tensor.normal_() if host_noise else None)
+                if host_noise:
+                    for _ in range(batch_number):
+                        engine.generator_phase_step(noise=noise_tensor.normal_())
+                else:
+                    engine.generator_phase_step(count=batch_number)
                 for p in detector.parameters():  # src/vgan.py:319-320 (every step there): freezes the detector for good
                     p.requires_grad = False
                 encoder_trainable = False
