@@ -66,6 +66,81 @@ struct G64 {
         }
     }
 };
+// 64x64 tile on EIGHT waves: two groups of 2 x 2 waves, group g multiplying the k16 steps 2 g, 2 g + 1 of every K tile (register
+// staging as GemmBF3: four 16-byte pieces per thread instead of eight); group 1 hands its accumulator to group 0 at the end.
+struct K2 {
+    static constexpr int BK = 64, ROWB = (BK + 8) * 2, PART = 64 * ROWB, BUF = 4 * PART, kLdsBytes = 2 * BUF;
+    typedef char __attribute__((address_space(3))) lds_c;
+    static constexpr int kThreads = 512;
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K, char* lds_generic,
+                                               f32x16& acc) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int grp = wave >> 2, w4 = wave & 3;
+        const int wm0 = (w4 >> 1) * 32, wn0 = (w4 & 1) * 32;
+        const int fi = lane & 31, fh = lane >> 5;
+        // staging: 4 parts x 64 rows x 8 pieces = 2048 pieces / 512 threads = 4: piece f = tid + 512 r -> part f >> 9 ... use part = r
+        const char* src[4];
+        int lofs;
+        {
+            const int row = tid >> 3, q = tid & 7;
+            const long ra = (long)min(m0 + row, M - 1) * lda + 8 * q, rb = (long)min(n0 + row, N - 1) * ldb + 8 * q;
+            src[0] = reinterpret_cast<const char*>(Ah + ra);
+            src[1] = reinterpret_cast<const char*>(Al + ra);
+            src[2] = reinterpret_cast<const char*>(Bh + rb);
+            src[3] = reinterpret_cast<const char*>(Bl + rb);
+            lofs = row * ROWB + q * 16;
+        }
+        u32x4 v[4];
+        auto load = [&](int k0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const u32x4*>(src[p] + 2 * (long)k0);
+        };
+        auto store = [&](lds_c* buf) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *(lds_u4*)(buf + p * PART + lofs) = v[p];
+        };
+        const int nk = K / BK;
+        load(0);
+        store(lds);
+        if (nk > 1) load(BK);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const lds_c* buf = lds + (kt & 1) * BUF;
+            const lds_c* pa = buf + (wm0 + fi) * ROWB + fh * 16 + grp * 64;
+            const lds_c* pb = buf + 2 * PART + (wn0 + fi) * ROWB + fh * 16 + grp * 64;
+            u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ah[s] = *(const lds_u4*)(pa + s * 32);
+                al[s] = *(const lds_u4*)(pa + PART + s * 32);
+                bh[s] = *(const lds_u4*)(pb + s * 32);
+                bl[s] = *(const lds_u4*)(pb + PART + s * 32);
+            }
+            if (kt + 1 < nk) store(lds + ((kt & 1) ^ 1) * BUF);
+            if (kt + 2 < nk) load((kt + 2) * BK);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[s]), xl = __builtin_bit_cast(bf16x8, al[s]);
+                const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[s]), yl = __builtin_bit_cast(bf16x8, bl[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_iglp_opt(0);
+            __syncthreads();
+        }
+        lds_f* xch = (lds_f*)lds;
+        if (grp == 1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[(w4 * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        if (grp == 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += xch[(w4 * 16 + r) * 64 + lane];
+    }
+};
 struct B64 {
     static constexpr int kLdsBytes = GemmBF3<64>::kLdsBytes;
     __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
@@ -73,24 +148,25 @@ struct B64 {
         GemmBF3<64>::run<false>(Ah, Al, lda, Bh, Bl, ldb, m0, n0, M, N, K, lds, nullptr, acc);
     }
 };
-template <class G>
-__global__ __launch_bounds__(256, 2) void k(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out) {
+template <class G, int NT>
+__global__ __launch_bounds__(NT, 2) void k(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out) {
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     const int r0 = (blockIdx.x / tiles_per_row) * 64, c0 = (blockIdx.x % tiles_per_row) * 64;
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     G::run(Zh, Zl, kp, Zh, Zl, kp, r0, c0, N, N, kp, lds, acc);
-    for (int r = 0; r < 16; ++r) out[((size_t)blockIdx.x * 16 + r) * 256 + threadIdx.x] = acc[r];
+    if (threadIdx.x < 256)
+        for (int r = 0; r < 16; ++r) out[((size_t)blockIdx.x * 16 + r) * 256 + threadIdx.x] = acc[r];
 }
-template <class G>
+template <class G, int NT = 256>
 static void bench(const char* name, const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int ntiles, float* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int tpr = N / 64;
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k<G>, dim3(ntiles), dim3(256), 0, 0, Zh, Zl, kp, N, tpr, out);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<G, NT>), dim3(ntiles), dim3(NT), 0, 0, Zh, Zl, kp, N, tpr, out);
     hipEventRecord(e0);
     const int it = 50;
-    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(k<G>, dim3(ntiles), dim3(256), 0, 0, Zh, Zl, kp, N, tpr, out);
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL((k<G, NT>), dim3(ntiles), dim3(NT), 0, 0, Zh, Zl, kp, N, tpr, out);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-6s tiles=%d: %.1f us/launch, %.1f algorithmic TFLOP/s\n", name, ntiles, ms / it * 1e3, 2.0 * 64 * 64 * kp * ntiles / (ms / it * 1e-3) / 1e12);
@@ -98,12 +174,13 @@ static void bench(const char* name, const unsigned short* Zh, const unsigned sho
 int main() {
     const int N = 2048, kp = 832;
     unsigned short *Zh, *Zl;
-    float *o1, *o2;
+    float *o1, *o2, *o3;
     hipMalloc(&Zh, (size_t)N * kp * 2);
     hipMalloc(&Zl, (size_t)N * kp * 2);
     const size_t no = (size_t)528 * 16 * 256;
     hipMalloc(&o1, no * 4);
     hipMalloc(&o2, no * 4);
+    hipMalloc(&o3, no * 4);
     std::vector<unsigned short> h((size_t)N * kp);
     for (auto& v : h) v = 0x3F00 + rand() % 128 + ((rand() & 1) << 15);
     hipMemcpy(Zh, h.data(), h.size() * 2, hipMemcpyHostToDevice);
@@ -112,6 +189,7 @@ int main() {
     for (int nt : {256, 392, 512, 528}) {
         bench<B64>("base", Zh, Zl, kp, N, nt, o1);
         bench<G64>("glds", Zh, Zl, kp, N, nt, o2);
+        bench<K2, 512>("8waves", Zh, Zl, kp, N, nt, o3);
     }
     std::vector<float> a(no), b(no);
     hipMemcpy(a.data(), o1, no * 4, hipMemcpyDeviceToHost);
@@ -119,5 +197,9 @@ int main() {
     double md = 0, mx = 0;
     for (size_t i = 0; i < no; ++i) { md = fmax(md, fabs((double)a[i] - b[i])); mx = fmax(mx, fabs((double)a[i])); }
     printf("max |base - glds| = %.3g (max |value| %.3g)\n", md, mx);
+    hipMemcpy(b.data(), o3, no * 4, hipMemcpyDeviceToHost);
+    md = 0;
+    for (size_t i = 0; i < no; ++i) md = fmax(md, fabs((double)a[i] - b[i]));
+    printf("max |base - 8waves| = %.3g\n", md);
     return 0;
 }
