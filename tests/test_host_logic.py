@@ -327,3 +327,16 @@ def test_vgan_kl_fit_device_feed_runs_on_cpu_provider():
         assert len(hist[-1][0]) == 7 and np.isfinite(hist[-1][0]).all() and np.isfinite(hist[-1][1][1:]).all()
     assert hist[0][0] == hist[1][0] and hist[0][1][1:] == hist[1][1][1:]
     MMDLossConstrained.__init__.__defaults__[0].bandwidth = None
+
+
+def test_run_steps_needs_the_device_noise_stream():
+    """Several steps per call are only defined when the engine draws its own noise; with host-provided noise the per-step
+    feed is the contract (set_noise + step), and run_steps(1) is that single step."""
+    g = load_golden("f2_step_c1.npz")
+    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], 128, 1)
+    eng.set_epoch_batches(torch.arange(128).view(1, 128))
+    eng.set_noise(torch.as_tensor(g["noise"]))
+    eng.run_steps(1)
+    assert eng.steps_done == 1
+    with pytest.raises(ValueError):
+        eng.run_steps(2)

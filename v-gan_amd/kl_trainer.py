@@ -278,8 +278,8 @@ class KLStepEngine:
         self._run(("d", bool(train_encoder)), lambda: self._detector_body(bool(train_encoder)), self._count(count, idx, noise))
 
     def _count(self, count, idx, noise):
-        if count != 1 and (idx is not None or noise is not None):
-            raise ValueError("several steps per call need the resident feed: no per-step indices or noise")
+        if count != 1 and (idx is not None or noise is not None or self.noise_mode != "device"):
+            raise ValueError("several steps per call need the resident feed and the device noise stream: no per-step indices or noise")
         return int(count)
 
     def _detector_body(self, train_encoder):

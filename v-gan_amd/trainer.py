@@ -610,6 +610,8 @@ class NoKLStepEngine:
         Host-provided noise (`set_noise`) is per step by nature: there, and while the engine is still eager, this is a loop
         over step()."""
         count = int(count)
+        if count > 1 and self.noise_mode != "device":
+            raise ValueError("run_steps needs the device noise stream: host-provided noise is set per step (set_noise + step)")
         m = self.steps_per_graph
         while count > 0:
             if (count >= m and m > 1 and self.use_graph and self.has_bw and self.steps_done > 0 and self.noise_mode == "device" and
