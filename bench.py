@@ -122,8 +122,13 @@ def kernel_rooflines(eng):
     # the Gram launch as the step issues it: XY and YY tiles only when the X-X tiles run in another launch (trainer.py); its
     # algorithmic flop = the pairs it covers x 2 d: n^2 (XY) + n (n + 1) / 2 (YY upper triangle); row-sharded: 2 nl n
     pairs = (n * n + n * (n + 1) / 2) if eng.world == 1 else 2.0 * nl * n
-    split = eng.n_main < eng.tiles.shape[0]   # the X-X tiles run in another launch (trainer.py: the M_4 launch carries them)
-    main_flop = 2.0 * D_FEAT * pairs if split else flop
+    split = eng.n_main < eng.tiles.shape[0]   # some X-X tiles run in another launch (trainer.py: the M_4 launch carries them)
+    # the Gram launch holds every XY / YY tile and as many X-X tiles as it has free slots for; the late X-X tiles' share of the
+    # X-X block's algorithmic flop goes with them
+    slots = (eng.tiles[:, 4] & 3).cpu()
+    xx_total, xx_late = int((slots == 0).sum()), int((slots[eng.n_main:] == 0).sum())
+    late_flop = (flop - 2.0 * D_FEAT * pairs) * xx_late / max(xx_total, 1)
+    main_flop = flop - late_flop if split else flop
     if eng.gram_tile == 64 and split:
         tiles64 = eng.tiles[:eng.n_main]
     ms = time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, tiles64, False, Wg, n + lo, part64))
@@ -139,7 +144,7 @@ def kernel_rooflines(eng):
                                                   tile=eng.gram_tile))
         out[gname] = {"ms": ms, "tflops": main_flop / (ms * 1e-3) / 1e12, "flop": main_flop, "tiles": int(eng.n_main)}
         if split:
-            xx_flop = flop - main_flop
+            xx_flop = late_flop
             ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[eng.n_main:], None, None, 0,
                                                       eng.partial[eng.n_main:], tile=eng.gram_tile))
             out[gname + " [X-X tiles alone]"] = {"ms": ms, "tflops": xx_flop / (ms * 1e-3) / 1e12, "flop": xx_flop,

@@ -27,7 +27,7 @@ extern "C" {
 #define VGAN_ERR_ARG 1  /* bad shape / null pointer / unsupported configuration */
 #define VGAN_ERR_HIP 2  /* a HIP runtime call or launch failed */
 
-#define VGAN_ABI_VERSION 3
+#define VGAN_ABI_VERSION 4
 
 typedef void* vgan_stream_t; /* hipStream_t */
 
@@ -223,10 +223,11 @@ typedef struct vgan_finalize_job {
     uint64_t* step_counter;
     int32_t ntiles, chunks, n, d;
     float weight, accum_scale;
-    /* mode 0: the whole tail.  The X-X tiles of the Gram may be computed LATER in the step than the launch the tail rides in
-     * (vgan_linear_backward_params_xx); the tail is then split: mode 1 = everything but the X-X block sum, over tiles
-     * [0, ntiles_main) -- column keys, Sxy, Syy, the step counter; the loss so far is parked in stats[3] -- and mode 2 = the
-     * X-X block sum over tiles [ntiles_main, ntiles), the loss and its accumulator (rides in vgan_gemm_grouped_ex, `fold`). */
+    /* mode 0: the whole tail.  Some X-X tiles of the Gram may be computed LATER in the step than the launch the tail rides in
+     * (vgan_linear_backward_params_xx); the tail is then split: mode 1 = everything over the tiles [0, ntiles_main) (the Gram
+     * launch's: all XY / YY tiles and any X-X tiles it had room for) -- column keys, block sums, the step counter; the loss so
+     * far is parked in stats[3], the X-X sum so far in stats[0] -- and mode 2 = the X-X sums of the late tiles
+     * [ntiles_main, ntiles), the loss and its accumulator (rides in vgan_gemm_grouped_ex, `fold`). */
     int32_t mode, ntiles_main;
 } vgan_finalize_job;
 /* dZ[i - wrow0, :] = 2 (rowsum(Wg_i) z_i - Wg_i . Z) for the nr rows starting at wrow0;
@@ -280,6 +281,15 @@ int vgan_mmd_backward_bf3_rm(const uint16_t* Wh, const uint16_t* Wl, int ldw, in
                              int p, const float* mul, int ldmul, const float* mul_shift, float* out, int ldo,
                              int splits, int64_t slab_stride, int tile, const vgan_finalize_job* finalize,
                              vgan_stream_t stream);
+/* vgan_mmd_backward_bf3_rm on 64-wide tiles with a few X-X tiles of the Gram (struct vgan_xx_job; identity row map) riding in
+ * the launch as surplus workgroups: the backward launch of the training step fills 416 of the chip's 512 workgroup slots for
+ * 25 us, so up to ~90 eight-microsecond tiles cost it nothing.  The tiles' partial sums are complete when the launch is;
+ * a `finalize` job in the same launch must therefore not cover them (vgan_finalize_job.mode 1 / 2). */
+int vgan_mmd_backward_bf3_rm_xx(const uint16_t* Wh, const uint16_t* Wl, int ldw, int kn, const uint16_t* Zh,
+                                const uint16_t* Zl, int kp, int zrows, const float* Z, int ldz, int wrow0, int nr,
+                                int p, const float* mul, int ldmul, const float* mul_shift, float* out, int ldo,
+                                int splits, int64_t slab_stride, const vgan_finalize_job* finalize,
+                                const struct vgan_xx_job* xx, vgan_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * Grouped small products: up to VGAN_GEMM_MAX_GROUP independent row-major GEMMs in one launch.
  * Generator_big (src/models/Generator.py:61-66) has no activation between its Linear layers, so its

@@ -204,21 +204,21 @@ class CpuOps:
                 colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
             self.mmd_loss(stats, colkey if colpart is not None else None, n, d, weight, loss, loss_accum, accum_scale, step_counter)
             return
-        # split tail (include/vgan_hip.h): mode 1 = all but the X-X block sum, mode 2 = the X-X block sum and the loss
+        # split tail (include/vgan_hip.h): mode 1 = everything over the Gram launch's tiles, mode 2 = the late X-X sums and the loss
         st = torch.zeros(4, dtype=torch.float64)
         if mode == 1:
             self.mmd_reduce(partial[:ntiles_main], tiles[:ntiles_main], st, True)
-            v = (-2.0 * float(st[1]) + float(st[2])) / (float(n) * n)
+            v = (float(st[0]) - 2.0 * float(st[1]) + float(st[2])) / (float(n) * n)
             if colpart is not None:
                 colkey.copy_(torch.as_tensor(_np(colpart).view(np.uint64).reshape(chunks, d).max(axis=0).view(np.int64)))
                 vals = (_np(colkey).view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32)
                 v += weight * float(np.mean(1.0 - vals.astype(np.float64)))
-            stats[1], stats[2], stats[3] = float(st[1]), float(st[2]), v
+            stats[0], stats[1], stats[2], stats[3] = float(st[0]), float(st[1]), float(st[2]), v
             if step_counter is not None:
                 step_counter += 1
         else:
             self.mmd_reduce(partial[ntiles_main:], tiles[ntiles_main:], st, True)
-            stats[0] = float(st[0])
+            stats[0] = float(stats[0]) + float(st[0])
             v = float(stats[3]) + float(st[0]) / (float(n) * n)
             loss.fill_(v)
             if loss_accum is not None:
@@ -400,12 +400,15 @@ class CpuOps:
         out[:nr, :p].copy_(torch.as_tensor(r))
 
     def mmd_backward_bf3_rm(self, Wh, Wl, Zh, Zl, zrows, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
-                            tile=0):
+                            tile=0, xx=None):
         kn = (int(zrows) + 63) // 64 * 64
         ZTh = torch.zeros(Zh.shape[1], kn, dtype=torch.int16)
         ZTl = torch.zeros(Zh.shape[1], kn, dtype=torch.int16)
         ZTh[:, :zrows], ZTl[:, :zrows] = Zh[:zrows].t(), Zl[:zrows].t()
         self.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits, slab_stride, finalize, mul_shift, tile)
+        if xx is not None:  # X-X tiles riding in the launch: their sums are NOT seen by the tail of the same launch (it ran above)
+            n = xx["Dh"].shape[0] // 2
+            self.mmd_gram_bf3(xx["Dh"], xx["Dl"], xx["dsq"], n, xx["bw"], xx["tiles"], None, None, 0, xx["partial"])
 
     def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):
         return int(self.lib.vgan_mmd_backward_bf3_tile(int(nr), int(p), int(splits), int(tile)))

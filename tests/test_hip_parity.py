@@ -771,6 +771,23 @@ def test_backward_bf3_rowmajor_operand_equals_transposed_operand(ops, n, d, nr_o
     want = 2.0 * (w64.sum(1, keepdim=True) * Z[wrow0:wrow0 + nr, :d].double() - w64 @ z64) * (mul[:, :d].double() + shift[:d].double())
     got = b.sum(0)[:, :d].double()
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    if tile != 128 and nr_of == 1:
+        # the same launch carrying X-X tiles of the Gram as surplus workgroups (vgan_mmd_backward_bf3_rm_xx): the product is
+        # untouched and the tiles' sums equal those of the Gram launch on the same tiles, bit for bit
+        sq = torch.empty(N, device="cuda")
+        ops.row_sqnorm(Z, sq, dp)
+        bw = torch.full((1,), float(d), device="cuda")
+        table = ops.build_tiles(n, 1)
+        xx_tiles = table[(table[:, 4] & 3) == 0][-5:].contiguous()
+        want_part, got_part = torch.zeros(5, 4, device="cuda"), torch.full((5, 4), float("nan"), device="cuda")
+        ops.mmd_gram_bf3(Zh, Zl, sq, n, bw, xx_tiles, None, None, 0, want_part)
+        c = torch.full((splits, nr, dp), float("nan"), device="cuda")
+        ops.mmd_backward_bf3_rm(Wh, Wl, Zh, Zl, N, Z, wrow0, nr, d, mul, c[0], splits, nr * dp, mul_shift=shift, tile=64,
+                                xx=ops.xx_job(Zh, Zl, sq, xx_tiles, bw, got_part))
+        torch.cuda.synchronize()
+        if tile == 64:
+            assert torch.equal(c[:, :, :d], b[:, :, :d])
+        assert torch.equal(got_part[:, 0], want_part[:, 0]) and float(want_part[:, 0].abs().min()) > 0
 
 
 @pytest.mark.parametrize("mode", ["collapsed"])

@@ -115,7 +115,8 @@ def test_xx_tiles_riding_in_the_forward_launch_equal_the_gram_launch(monkeypatch
     assert torch.equal(res["1"][1], res["0"][1])  # the X-X sums feed the reported loss only, never a gradient
 
 
-def test_xx_tiles_in_the_m4_launch_with_split_step_tail(monkeypatch):
+@pytest.mark.parametrize("carrier", ["backward", "m4"])
+def test_xx_tiles_in_the_m4_launch_with_split_step_tail(monkeypatch, carrier):
     """bf16x3 mode: the X-X tiles computed inside the M_4 launch (two launches after the MMD backward that carries the step
     tail) with the tail split in two -- everything but the X-X block sum early, the X-X sum and the loss in the first chain
     launch of the backward -- give the same per-step losses, statistics and parameters as the unsplit schedule (CPU provider,
@@ -128,10 +129,15 @@ def test_xx_tiles_in_the_m4_launch_with_split_step_tail(monkeypatch):
     ref = orc.NoKLTrainer([g[f"param0_{i}"].astype(np.float64) for i in range(8)])
     want = [ref.step(g["data"][idx[t]].astype(np.float64), noise[t].astype(np.float64))["loss"] for t in range(7)]
     res = {}
+    # 16 XY + 10 YY + 10 X-X tiles: the Gram launch is given 30 slots -- 4 X-X tiles early, 6 behind M_4 (on the GPU it has
+    # 512, and at this size everything would fit the one launch)
+    monkeypatch.setenv("VGAN_GRAM_SLOTS", "30")
+    monkeypatch.setenv("VGAN_XX_LATE", carrier)   # the late tiles ride in the MMD backward launch (default) or behind M_4
     for late in ("1", "0"):
         monkeypatch.setenv("VGAN_XX_IN_M4", late)
         eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["data"], n, nb, mmd_precision="bf16x3")
-        assert eng.xx_in_m4 == (late == "1")
+        assert eng.xx_in_m4 == (late == "1") and (eng.n_main, eng.tiles.shape[0]) == ((30, 36) if late == "1" else (36, 36))
+        assert eng.xx_late_in_backward == (late == "1" and carrier == "backward")
         losses, sxx = [], []
         for t in range(7):
             if t % nb == 0:

@@ -141,6 +141,85 @@ struct K2 {
             for (int r = 0; r < 16; ++r) acc[r] += xch[(w4 * 16 + r) * 64 + lane];
     }
 };
+// 64 x 128 tile on eight waves: waves 0-3 the left 64 columns, 4-7 the right 64, each group 2 x 2 waves of 32 x 32; the A
+// rows are staged once for both halves (48 KB of fill per K tile instead of 64 KB for two 64x64 workgroups), one workgroup per CU.
+struct W128 {
+    static constexpr int BK = 64, ROWB = (BK + 8) * 2, PA = 64 * ROWB, PB = 128 * ROWB, BUF = 2 * PA + 2 * PB, kLdsBytes = 2 * BUF;
+    typedef char __attribute__((address_space(3))) lds_c;
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K, char* lds_generic,
+                                               f32x16& acc) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int half = wave >> 2, w4 = wave & 3;
+        const int wm0 = (w4 >> 1) * 32, wn0 = half * 64 + (w4 & 1) * 32;
+        const int fi = lane & 31, fh = lane >> 5;
+        // pieces: A parts 2 x 64 rows x 8 = 1024, B parts 2 x 128 x 8 = 2048: 3072 / 512 threads = 6 per thread
+        const char* src[6];
+        int dst[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int f = tid + 512 * r;  // 0..3071
+            if (f < 1024) {               // A: part f >> 9, row (f >> 3) & 63
+                const int part = f >> 9, row = (f >> 3) & 63, q = f & 7;
+                src[r] = reinterpret_cast<const char*>((part ? Al : Ah) + (long)min(m0 + row, M - 1) * lda + 8 * q);
+                dst[r] = part * PA + row * ROWB + q * 16;
+            } else {
+                const int g = f - 1024, part = g >> 10, row = (g >> 3) & 127, q = g & 7;
+                src[r] = reinterpret_cast<const char*>((part ? Bl : Bh) + (long)min(n0 + row, N - 1) * ldb + 8 * q);
+                dst[r] = 2 * PA + part * PB + row * ROWB + q * 16;
+            }
+        }
+        u32x4 v[6];
+        auto load = [&](int k0) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) v[r] = *reinterpret_cast<const u32x4*>(src[r] + 2 * (long)k0);
+        };
+        auto store = [&](lds_c* buf) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) *(lds_u4*)(buf + dst[r]) = v[r];
+        };
+        const int nk = K / BK;
+        load(0);
+        store(lds);
+        if (nk > 1) load(BK);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const lds_c* buf = lds + (kt & 1) * BUF;
+            const lds_c* pa = buf + (wm0 + fi) * ROWB + fh * 16;
+            const lds_c* pb = buf + 2 * PA + (wn0 + fi) * ROWB + fh * 16;
+            u32x4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ah[s] = *(const lds_u4*)(pa + s * 32);
+                al[s] = *(const lds_u4*)(pa + PA + s * 32);
+                bh[s] = *(const lds_u4*)(pb + s * 32);
+                bl[s] = *(const lds_u4*)(pb + PB + s * 32);
+            }
+            if (kt + 1 < nk) store(lds + ((kt & 1) ^ 1) * BUF);
+            if (kt + 2 < nk) load((kt + 2) * BK);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[s]), xl = __builtin_bit_cast(bf16x8, al[s]);
+                const bf16x8 yh = __builtin_bit_cast(bf16x8, bh[s]), yl = __builtin_bit_cast(bf16x8, bl[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_iglp_opt(0);
+            __syncthreads();
+        }
+    }
+};
+template <class G>
+__global__ __launch_bounds__(512, 2) void kw(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out) {
+    __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
+    const int r0 = (blockIdx.x / tiles_per_row) * 64, c0 = (blockIdx.x % tiles_per_row) * 128;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    G::run(Zh, Zl, kp, Zh, Zl, kp, r0, c0, N, N, kp, lds, acc);
+    for (int r = 0; r < 16; ++r) out[((size_t)blockIdx.x * 16 + r) * 512 + threadIdx.x] = acc[r];
+}
 struct B64 {
     static constexpr int kLdsBytes = GemmBF3<64>::kLdsBytes;
     __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
@@ -186,6 +265,19 @@ int main() {
     hipMemcpy(Zh, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     for (auto& v : h) v = 0x3B00 + rand() % 128;
     hipMemcpy(Zl, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    {
+        float* ow; hipMalloc(&ow, (size_t)264 * 16 * 512 * 4);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int nt : {128, 200, 256, 264}) {
+            for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kw<W128>, dim3(nt), dim3(512), 0, 0, Zh, Zl, kp, N, N / 128, ow);
+            hipEventRecord(e0);
+            for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(kw<W128>, dim3(nt), dim3(512), 0, 0, Zh, Zl, kp, N, N / 128, ow);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("64x128 tiles=%d (= %d 64x64 tiles of work): %.1f us/launch, %.1f algorithmic TFLOP/s\n", nt, 2 * nt, ms / 50 * 1e3,
+                   2.0 * 64 * 128 * kp * nt / (ms / 50 * 1e-3) / 1e12);
+        }
+    }
     for (int nt : {256, 392, 512, 528}) {
         bench<B64>("base", Zh, Zl, kp, N, nt, o1);
         bench<G64>("glds", Zh, Zl, kp, N, nt, o2);

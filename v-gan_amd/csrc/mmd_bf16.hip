@@ -12,6 +12,7 @@
 // the transposed copy, for the backward product, whose B fragment needs 8 consecutive k (= Z rows) per lane.
 #include "gemm_bf3.hpp"
 #include "mmd_common.hpp"
+#include "mmd_xx.hpp"
 
 namespace vgan {
 
@@ -305,14 +306,21 @@ __global__ __launch_bounds__(kBlock, BK == 64 ? 2 : 3) void mmd_backward_bf3_ker
                                                                     const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                     int ptiles, const float* __restrict__ mul, int ldmul,
                                                                     const float* __restrict__ mul_shift, float* __restrict__ out, int ldo,
-                                                                    int kchunk, long slab_stride, vgan_finalize_job job) {
+                                                                    int kchunk, long slab_stride, vgan_finalize_job job, int nfin,
+                                                                    XXJob xx) {
     using G = GemmBF3<BK>;
-    __shared__ __attribute__((aligned(16))) char lds[RM ? G::kLdsBytesT : G::kLdsBytes];
+    constexpr int kBytes = (RM ? G::kLdsBytesT : G::kLdsBytes) > G::kLdsBytes ? (RM ? G::kLdsBytesT : G::kLdsBytes) : G::kLdsBytes;
+    __shared__ __attribute__((aligned(16))) char lds[kBytes];
     __shared__ float rs[64];
     // XCD-aware order as in mmd_backward_kernel: down 4 row panels, then the next feature panel
     const int gx = ptiles, gy = (nr + 63) / 64, total = gx * gy;
-    if ((int)blockIdx.x >= total) {  // the one surplus workgroup column of the launch: the step tail (see vgan_finalize_job)
-        if (blockIdx.y == 0) finalize_body(job);
+    if ((int)blockIdx.x >= total) {  // surplus workgroups of the launch (slab 0 only): the step tail (see vgan_finalize_job), then
+        if (blockIdx.y != 0) return;  // X-X tiles of the Gram that found no slot in its own launch (vgan_mmd_backward_bf3_rm_xx)
+        const int extra = (int)blockIdx.x - total;
+        if (extra < nfin)
+            finalize_body(job);
+        else if constexpr (BK == 64)
+            xx_tile_body(xx, extra - nfin, lds, rs);
         return;
     }
     const int xcd = blockIdx.x % 8, kidx = blockIdx.x / 8;
@@ -472,7 +480,7 @@ extern "C" int vgan_mmd_backward_bf3_tile(int nr, int p, int splits, int tile) {
 static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* Bh, const uint16_t* Bl, int kn, int kp,
                                int zrows, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
                                const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
-                               const vgan_finalize_job* finalize, vgan_stream_t stream) {
+                               const vgan_finalize_job* finalize, vgan_stream_t stream, const vgan_xx_job* xxjob = nullptr) {
     VGAN_CHECK_ARG(Wh && Wl && Bh && Bl && Z && out && nr > 0 && p > 0 && kn > 0 && kn % 64 == 0 && kp >= p && kp % 64 == 0);
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
     VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(Bh) && aligned16(Bl) && ldw % 8 == 0);
@@ -486,6 +494,14 @@ static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, i
         job = *finalize;
     }
     hipStream_t st = (hipStream_t)stream;
+    XXJob xx{};
+    if (xxjob != nullptr) {
+        const vgan_xx_job& j = *xxjob;
+        VGAN_CHECK_ARG(rm && tile == 64 && j.Dh && j.Dl && j.dsq && j.tiles && j.bw && j.partial && j.ntiles > 0 && j.ldd % 64 == 0 &&
+                       aligned16(j.Dh) && aligned16(j.Dl) && (reinterpret_cast<uintptr_t>(j.partial) & 15) == 0);
+        xx = XXJob{j.Dh, j.Dl, j.dsq, nullptr, nullptr, reinterpret_cast<const TileDesc*>(j.tiles), j.bw, j.partial, j.ldd, 1, 0, j.ntiles, 0};
+    }
+    const int nfin = finalize != nullptr ? 1 : 0;
     if (vgan_mmd_backward_bf3_tile(nr, p, splits, tile) == 128) {
         const int pt = (p + 127) / 128;
         dim3 grid(pt * ((nr + 127) / 128) + (finalize != nullptr ? 1 : 0), splits);
@@ -499,13 +515,13 @@ static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, i
         return VGAN_OK;
     }
     const int ptiles = (p + 63) / 64;
-    dim3 grid(ptiles * ((nr + 63) / 64) + (finalize != nullptr ? 1 : 0), splits);
+    dim3 grid(ptiles * ((nr + 63) / 64) + nfin + xx.ntiles, splits);
     if (rm)
         hipLaunchKernelGGL((mmd_backward_bf3_kernel<64, true>), grid, dim3(kBlock), 0, st, Wh, Wl, ldw, Bh, Bl, kn, ldb, zrows, Z, ldz, wrow0, nr,
-                           p, ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job);
+                           p, ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job, nfin, xx);
     else
         hipLaunchKernelGGL((mmd_backward_bf3_kernel<64, false>), grid, dim3(kBlock), 0, st, Wh, Wl, ldw, Bh, Bl, kn, ldb, 0, Z, ldz, wrow0, nr, p,
-                           ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job);
+                           ptiles, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, job, nfin, xx);
     VGAN_CHECK_LAUNCH();
     return VGAN_OK;
 }
@@ -516,6 +532,15 @@ extern "C" int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int
                                      const vgan_finalize_job* finalize, vgan_stream_t stream) {
     return launch_backward_bf3(0, Wh, Wl, ldw, ZTh, ZTl, kn, kp, 0, Z, ldz, wrow0, nr, p, mul, ldmul, mul_shift, out, ldo, splits, slab_stride,
                                tile, finalize, stream);
+}
+
+extern "C" int vgan_mmd_backward_bf3_rm_xx(const uint16_t* Wh, const uint16_t* Wl, int ldw, int kn, const uint16_t* Zh, const uint16_t* Zl,
+                                           int kp, int zrows, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
+                                           const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride,
+                                           const vgan_finalize_job* finalize, const vgan_xx_job* xx, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(xx != nullptr);
+    return launch_backward_bf3(1, Wh, Wl, ldw, Zh, Zl, kn, kp, zrows, Z, ldz, wrow0, nr, p, mul, ldmul, mul_shift, out, ldo, splits,
+                               slab_stride, 64, finalize, stream, xx);
 }
 
 extern "C" int vgan_mmd_backward_bf3_rm(const uint16_t* Wh, const uint16_t* Wl, int ldw, int kn, const uint16_t* Zh, const uint16_t* Zl,

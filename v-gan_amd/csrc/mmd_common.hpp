@@ -33,8 +33,9 @@ __device__ __forceinline__ void finalize_body(const vgan_finalize_job& job) {
     unsigned long long* __restrict__ step_counter = reinterpret_cast<unsigned long long*>(job.step_counter);
     const int ntiles = job.ntiles, chunks = job.chunks, n = job.n, d = job.d;
     const float weight = job.weight, accum_scale = job.accum_scale;
-    // split tail (vgan_finalize_job.mode): 1 = all but the X-X block sum, tiles [0, ntiles_main); 2 = the X-X block sum, tiles
-    // [ntiles_main, ntiles), and the loss.  stats[3] carries the loss-so-far from 1 to 2 in double precision.
+    // split tail (vgan_finalize_job.mode): 1 = everything over the tiles [0, ntiles_main) -- those of the Gram launch, which may
+    // include some X-X tiles; 2 = the block sums of the late tiles [ntiles_main, ntiles) (X-X only) and the loss.  stats[3]
+    // carries the loss-so-far and stats[0] the X-X sum so far from 1 to 2, in double precision.
     const int mode = job.mode;
     const int t_lo = mode == 2 ? job.ntiles_main : 0, t_hi = mode == 1 ? job.ntiles_main : ntiles;
     if (mode == 2) colpart = nullptr;
@@ -76,14 +77,15 @@ __device__ __forceinline__ void finalize_body(const vgan_finalize_job& job) {
             for (int q = 0; q < 5; ++q) t[q] += red[w][q];
         const double nn = (double)n * (double)n;
         if (mode == 1) {
+            stats[0] = t[0];
             stats[1] = t[1];
             stats[2] = t[2];
-            stats[3] = (-2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
+            stats[3] = (t[0] - 2.0 * t[1] + t[2]) / nn + (colpart ? (double)weight * t[4] / (double)d : 0.0);
             if (step_counter) step_counter[0] += 1ull;
         } else {
             double v;
             if (mode == 2) {
-                stats[0] = t[0];
+                stats[0] += t[0];
                 v = stats[3] + t[0] / nn;
             } else {
                 for (int q = 0; q < 4; ++q) stats[q] = t[q];

@@ -89,6 +89,7 @@ SIGNATURES = {
     "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p]),
     "vgan_mmd_backward_bf3_tile": (_i, [_i, _i, _i, _i]),
     "vgan_mmd_backward_bf3_rm": (_i, [_p, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p]),
+    "vgan_mmd_backward_bf3_rm_xx": (_i, [_p, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _p, _p, _p]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),
     "vgan_noise_normal": (_i, [_p, _i, _i, _i, _i, _u64, _p, _u64, _p]),
@@ -112,7 +113,7 @@ SIGNATURES = {
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

@@ -345,12 +345,21 @@ class HipOps:
                    "vgan_mmd_backward_bf3")
 
     def mmd_backward_bf3_rm(self, Wh, Wl, Zh, Zl, zrows, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
-                            tile=0):
-        """mmd_backward_bf3 on the ROW-MAJOR split images Zh, Zl [>= zrows, kp] (no transposed copies of Z)."""
+                            tile=0, xx=None):
+        """mmd_backward_bf3 on the ROW-MAJOR split images Zh, Zl [>= zrows, kp] (no transposed copies of Z).  xx: an xx_job() whose
+        X-X Gram tiles ride in the launch as surplus workgroups (64-wide tiles only)."""
         _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         kn = (int(zrows) + 63) // 64 * 64
         assert Wh.stride(0) >= kn and Zh.shape[0] >= zrows
+        if xx is not None:
+            assert tile in (0, 64)
+            _lib.check(self.lib.vgan_mmd_backward_bf3_rm_xx(_ptr(Wh), _ptr(Wl), Wh.stride(0), kn, _ptr(Zh), _ptr(Zl), Zh.stride(0), int(zrows),
+                                                            _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul, _ptr(mul_shift),
+                                                            _ptr(out), out.stride(0), int(splits), int(slab_stride),
+                                                            ctypes.byref(finalize) if finalize is not None else None, ctypes.byref(xx),
+                                                            self._stream()), "vgan_mmd_backward_bf3_rm_xx")
+            return
         _lib.check(self.lib.vgan_mmd_backward_bf3_rm(_ptr(Wh), _ptr(Wl), Wh.stride(0), kn, _ptr(Zh), _ptr(Zl), Zh.stride(0), int(zrows),
                                                      _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul, _ptr(mul_shift),
                                                      _ptr(out), out.stride(0), int(splits), int(slab_stride), int(tile),

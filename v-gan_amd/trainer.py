@@ -300,9 +300,27 @@ class NoKLStepEngine:
         self._xx_m4 = self._fold = None
         if self.overlap or self.xx_ride or self.xx_in_m4:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
+            if self.xx_in_m4:
+                # ... but only the X-X tiles the Gram launch has no free slot for: at two 74 KB workgroups per CU the chip holds
+                # 512 tiles at once, and a CU works through two of them in 13.3-14.1 us whether its neighbour has one or two
+                # (tools/ablate_bf3_glds.hip: 392 tiles 13.3 us, 512 tiles 14.1 us).  c3: 392 XY + YY tiles + 120 of the 136 X-X
+                # tiles in the Gram launch, 16 behind M_4 (+0.8 us on the Gram, -3 us on the carrier).
+                slots = int(os.environ.get("VGAN_GRAM_SLOTS", "512"))  # (tests force a split at small sizes with this)
+                self.n_main = min(self.tiles.shape[0], max(self.n_main, slots))
+                if self.n_main == self.tiles.shape[0]:
+                    self.xx_in_m4 = False  # everything fits the one launch: no carrier, one tail
         else:
             self.tiles = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile)
             self.n_main = self.tiles.shape[0]
+        # The few X-X tiles left over (c3: 16) ride in the MMD BACKWARD launch when it has free slots for them: that launch fills
+        # 416 of the 512 slots for 25 us, so eight-microsecond tiles on the other slots cost nothing, whereas behind M_4 even 16
+        # tiles stretch the launch from 8.5 to 12.1 us (a lone tile's latency, not their number).  The late half of the split
+        # tail (first chain launch of the backward) picks their sums up either way.
+        self.xx_late_in_backward = False
+        if self.xx_in_m4 and self.rm_backward and os.environ.get("VGAN_XX_LATE", "backward") == "backward":
+            late = self.tiles.shape[0] - self.n_main
+            bwd_wgs = ((d + 63) // 64) * ((nl + 63) // 64) * self.bsplits + 1
+            self.xx_late_in_backward = (ops.mmd_backward_bf3_tile(nl, d, self.bsplits, self.bwd_tile) == 64 and late <= 512 - bwd_wgs)
         # the first-call bandwidth needs sum(L) over ALL pairs: computed by every rank from the full table (no collective)
         # (the calibration launch is the fp32 kernel: 64-wide tiles)
         self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not (self.overlap or self.xx_ride or self.xx_in_m4)) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
@@ -449,11 +467,8 @@ class NoKLStepEngine:
         # M4[:d] = dlogits^T . [z|1]   (rows >= d stay zero: the homogeneous output coordinate carries no gradient)
         # (the library runs this long contraction on its tall-skinny 16-wave tiles; row slabs + a reduction launch, or
         # slab-summing staging loads in the consumers, were both measured slower)
-        if self.xx_in_m4:
-            if self._xx_m4 is None:
-                ntx = self.tiles.shape[0] - self.n_main
-                self._xx_m4 = ops.xx_job(self.Zh, self.Zl, self.sqn, self.tiles[self.n_main:], self.bw, self.partial[self.n_main:self.n_main + ntx])
-            ops.linear_backward_params_xx(self.dlogits_pad, self.z_own, self.M[4][:self.dp], self._xx_m4)
+        if self.xx_in_m4 and not self.xx_late_in_backward:
+            ops.linear_backward_params_xx(self.dlogits_pad, self.z_own, self.M[4][:self.dp], self._late_xx_job())
         else:
             ops.linear_backward_params(self.dlogits_pad, self.z_own, self.M[4][:self.dp], None)  # pad columns are zero: rows d.. of M_4 too
         if dist:
@@ -560,7 +575,8 @@ class NoKLStepEngine:
         if bf3:
             if self.rm_backward:
                 ops.mmd_backward_bf3_rm(self.Wh, self.Wl, self.Zh, self.Zl, 2 * n, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU,
-                                        self.bsplits, gstride, fin, mul_shift=self.center, tile=self.bwd_tile)
+                                        self.bsplits, gstride, fin, mul_shift=self.center, tile=self.bwd_tile,
+                                        xx=self._late_xx_job() if self.xx_late_in_backward else None)
             else:
                 ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
                                      gstride, fin, mul_shift=self.center, tile=self.bwd_tile)
@@ -571,6 +587,14 @@ class NoKLStepEngine:
         ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
         self._generator_backward_update(dist)
         self._join_prefetch()
+
+    def _late_xx_job(self):
+        """The X-X tiles the Gram launch had no slot for, as a job for the launch that carries them."""
+        if self._xx_m4 is None:
+            ntx = self.tiles.shape[0] - self.n_main
+            self._xx_m4 = self.ops.xx_job(self.Zh, self.Zl, self.sqn, self.tiles[self.n_main:], self.bw,
+                                          self.partial[self.n_main:self.n_main + ntx])
+        return self._xx_m4
 
     def _step_body(self):
         self._forward()
