@@ -91,17 +91,21 @@ def run_steps(eng, count, start_step):
         t += k
 
 
-def time_kernel(fn, iters=30):
-    """Average duration (ms) of one launch, HIP events on the stream the kernel is launched on."""
-    for _ in range(3):
+def time_kernel(fn, iters=30, repeats=5):
+    """Average duration (ms) of one launch, HIP events on the stream the kernel is launched on: `repeats` blocks of `iters`
+    back-to-back launches, the median block (single blocks scatter by ~5 % with the clock state they start in)."""
+    for _ in range(5):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+    blocks = []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        blocks.append(e0.elapsed_time(e1) / iters)
+    return sorted(blocks)[len(blocks) // 2]
 
 
 def kernel_rooflines(eng):
