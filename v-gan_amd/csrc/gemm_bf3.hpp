@@ -500,7 +500,7 @@ struct GemmBF3Big {
     // Row sums of A = Ah + Al from the fragments themselves (there are no staging registers to take them from): the waves
     // (grp, R, 0) and (grp, R, 1) read the same A fragments, so wave C sums the fragments of its k16 step 2 grp + C only --
     // 64 VALU operations per K tile and wave, issued beside the MFMAs.  (`v_dot2c_f32_bf16` against a vector of ones would be
-    // one instruction per pair, but returned wrong sums in this loop on gfx950 -- tools/dbg_rs.hip -- while the same
+    // one instruction per pair, but returned wrong sums in this loop on gfx950 -- tools/check_rowsum_big.hip -- while the same
     // instruction in a plain loop is exact; the shift / mask / add form is used.)
     __device__ static __forceinline__ float frag_sum(const u32x4& h, const u32x4& l, float s) {
 #pragma unroll
