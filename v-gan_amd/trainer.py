@@ -296,7 +296,9 @@ class NoKLStepEngine:
             self.Dh, self.Dl = torch.zeros(rows_total, self.kp, **i16), torch.zeros(rows_total, self.kp, **i16)
             self.dsq = torch.zeros(rows_total, **f32)
             ops.gather_rows_split(data, None, self.center, None, self.dsq, True, self.Dh, self.Dl, n=rows_total)
-        # the X-X tiles riding in the M_4 launch instead (warm operand: the step's own Zh / Zl X half, identity row map)
+        # X-X tiles outside the Gram launch, on a warm operand (the step's own Zh / Zl X half, identity row map).  `xx_in_m4` =
+        # "some X-X tiles are computed LATER in the step than the launch that carries the step tail" (the tail is then split);
+        # their carrier is the MMD backward launch when it has room (`xx_late_in_backward`), else the M_4 launch.
         self.xx_in_m4 = (self.bf3 and self.mode == "collapsed" and self.gram_tile == 64 and not self.overlap and not self.xx_ride and
                          ops.linear_backward_params_xx_supported(nl, self.e[0], dp) and os.environ.get("VGAN_XX_IN_M4", "1") == "1")
         self._xx_m4 = self._fold = None
@@ -306,7 +308,7 @@ class NoKLStepEngine:
                 # ... but only the X-X tiles the Gram launch has no free slot for: at two 74 KB workgroups per CU the chip holds
                 # 512 tiles at once, and a CU works through two of them in 13.3-14.1 us whether its neighbour has one or two
                 # (tools/ablate_bf3_glds.hip: 392 tiles 13.3 us, 512 tiles 14.1 us).  c3: 392 XY + YY tiles + 120 of the 136 X-X
-                # tiles in the Gram launch, 16 behind M_4 (+0.8 us on the Gram, -3 us on the carrier).
+                # tiles in the Gram launch, 16 left over.
                 slots = int(os.environ.get("VGAN_GRAM_SLOTS", "512"))  # (tests force a split at small sizes with this)
                 self.n_main = min(self.tiles.shape[0], max(self.n_main, slots))
                 if self.n_main == self.tiles.shape[0]:
@@ -568,7 +570,7 @@ class NoKLStepEngine:
         if self._fin is None:
             fin_args = (self.partial, self.tiles, self.colpart, ops.colmax_chunks(n), self.colkey, n, d, self.pen if self.rank == 0 else 0.0,
                         self.stats, self.loss, self.loss_accum, self.accum_scale, self.step_counter)
-            if self.xx_in_m4:  # the X-X block sum arrives two launches later: the tail is split (include/vgan_hip.h)
+            if self.xx_in_m4:  # part of the X-X block sum arrives later in the step: the tail is split (include/vgan_hip.h)
                 self._fin = ops.finalize_job(*fin_args, mode=1, ntiles_main=self.n_main)
                 self._fold = ops.finalize_job(*fin_args, mode=2, ntiles_main=self.n_main)
             else:
