@@ -9,11 +9,21 @@ One step = one VGAN_no_kl.fit step body (reference src/vgan.py:597-621) at the G
 -> upper_softmax -> U*X -> 5-bandwidth RBF MMD^2 (+penalty) -> backward -> Adadelta.  N > 1 shards
 the batch rows across ranks (exact data parallel; strong scaling: total work fixed).
 
+Timing: W untimed warm-up steps, then `--repeats` blocks of EXACTLY K steps, each bracketed by barrier +
+torch.cuda.synchronize() on both sides and reduced by MAX over ranks; `value` is the MEDIAN block (every block's rate is kept
+in `repeat_steps_per_s`).  Every timed block starts at an epoch boundary and one untimed block of the same K steps runs
+first, so the blocks replay exactly the HIP graphs a fit replays (16 steps per graph launch + one graph for the remainder).
+
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
-  roofline      the Gram/MMD kernel of the active precision mode against the MFMA peak of the instruction it issues
-                (durations measured here with HIP events); the other mode's kernels are timed beside it
-  cpu_baseline  the op-for-op PyTorch-CPU port of the reference step timed on this host's cores
+  roofline      the LONGEST MMD kernel of the active precision mode against the MFMA peak of the instruction it issues
+                (durations measured here with HIP events); every other MMD kernel, both modes, under `also`
+  fp32_mode     the same workload timed again with the fp32-MFMA kernels (the reference's own arithmetic is fp32)
+  cpu_baseline  the op-for-op PyTorch-CPU port of the reference step timed on this host's cores (rank 0, any N)
   parity        |loss_gpu - loss_cpu| on identical inputs (bar 1e-4)
+  extra         (default workload only) the larger BASELINE.json configurations in the same run: configs[3] (c4) and
+                configs[4] (c5: fp32 as BASELINE specifies, and the engine's bf16x3 choice), and with N > 1 the alternative
+                exchange schedules (c3: all-reduce overlapped with the next batch's X-X tiles; c4 / c5: replicated front
+                instead of the sharded one) -- so that ONE invocation per N yields every number of the scaling study
 """
 import argparse
 import json
@@ -28,7 +38,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 N_BATCH, D_FEAT, EPOCH_BATCHES, CONFIG = 1024, 784, 16, "c3"
-WORKLOADS = {  # --workload: the metric is quoted on c3; c4 / c5 are the larger BASELINE.json configurations (extra lines)
+WORKLOADS = {  # --workload: the metric is quoted on c3; c4 / c5 are the larger BASELINE.json configurations
     "c1": (128, 20, 16, "configs[0]: 2-Gaussian mixture, d=20, batch=128 (VGAN_no_kl step; launch-latency bound)"),
     "c2": (512, 166, 5, "configs[1]: ADBench 'musk' stand-in, d=166, batch=512 (VGAN_no_kl step)"),
     "c3": (1024, 784, 16, "configs[2]: MNIST-pixels-as-features stand-in, d=784, batch=1024 (VGAN_no_kl step)"),
@@ -37,7 +47,14 @@ WORKLOADS = {  # --workload: the metric is quoted on c3; c4 / c5 are the larger 
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
-WORKLOAD = "configs[2]: MNIST-pixels-as-features stand-in, d=784, batch=1024 (VGAN_no_kl step)"
+WORKLOAD = WORKLOADS["c3"][3]
+_DATA_CACHE = {}
+
+
+def select_workload(cfg):
+    global N_BATCH, D_FEAT, EPOCH_BATCHES, CONFIG, WORKLOAD
+    CONFIG = cfg
+    N_BATCH, D_FEAT, EPOCH_BATCHES, WORKLOAD = WORKLOADS[cfg]
 
 
 def parse():
@@ -45,17 +62,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed steps run right after graph capture so that the GPU clock has ramped (DVFS) before the "
                          "W warm-up steps; a fit runs for minutes, so the ramped state is the representative one")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--path", choices=["nokl", "kl"], default="nokl",
-                    help="nokl: the metric's VGAN_no_kl step (default); kl: VGAN.fit's detector step (SURVEY 8a10), an extra "
-                         "informational line -- eager launches, one GPU")
+                    help="nokl: the metric's VGAN_no_kl step (default); kl: VGAN.fit's step mix (SURVEY 8a10), an extra "
+                         "informational line, one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c4 / c5 / alternative-schedule legs of the default run")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3"], default=None,
                     help="MMD contraction mode (default: VGAN_MMD_PRECISION or the engine's 'auto' rule, bf16x3 at this size)")
+    ap.add_argument("--front", choices=["auto", "replicated", "sharded"], default=None,
+                    help="data-parallel front of the step (trainer.py; default: the engine's size rule)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -65,7 +86,10 @@ def build_engine(rank, world, use_graph, **engine_kw):
     from vgan_amd import synth
     from vgan_amd.ops import HipOps
     from vgan_amd.trainer import NoKLStepEngine
-    data = synth.synthetic_dataset(CONFIG)  # [EPOCH_BATCHES * batch, d] float32
+    if CONFIG not in _DATA_CACHE:  # (c5: 537 MB of numpy draws -- once per process, not once per leg)
+        _DATA_CACHE.clear()
+        _DATA_CACHE[CONFIG] = synth.synthetic_dataset(CONFIG)  # [EPOCH_BATCHES * batch, d] float32
+    data = _DATA_CACHE[CONFIG]
     params = synth.synthetic_generator_params(D_FEAT)
     gen = vgan_amd.Generator_big(synth.latent_size(D_FEAT), D_FEAT)
     with torch.no_grad():
@@ -109,59 +133,64 @@ def time_kernel(fn, iters=30, repeats=5):
 
 
 def kernel_rooflines(eng):
-    """Per-launch durations of the MFMA kernels of the MMD, as launched inside the step (both precision modes)."""
+    """Per-launch durations of the MFMA kernels of the MMD, as launched inside the step (both precision modes).
+    ALGORITHMIC flop per launch: 2 d per pair the launch covers.  One GPU: the Gram covers the 2 n^2 unique pairs
+    (XY block + upper triangles of XX and YY), the backward product W[n x 2n] . Z[2n x d] is 4 n^2 d.  A rank of a row-sharded
+    run covers (own Y rows) x (all columns) -- the symmetric YY pairs of another rank's rows are ITS work too, counted where
+    they are computed -- plus its share of the XX triangle."""
     ops, n, p, d = eng.ops, eng.n, eng.dp, eng.d
     nl, lo = eng.nl, eng.lo
-    # algorithmic FLOPs (SURVEY 8d): forward 2n^2 unique pairs x 2p = 4 n^2 p ; backward Gs[n x 2n] . Z[2n x p] = 4 n^2 p
-    flop = 4.0 * n * n * D_FEAT / eng.world
+    iters = 30 if n <= 2048 else 6
+    tl = eng.tiles.cpu()
+    edge = eng.gram_tile
+
+    def pairs_of(t):  # pairs a tile table covers, mirrored halves of a symmetric tile counted once
+        r = (torch.minimum(t[:, 0] + edge, t[:, 2]) - t[:, 0]).double()
+        c = (torch.minimum(t[:, 1] + edge, t[:, 3]) - t[:, 1]).double()
+        diag = (t[:, 0] % n == t[:, 1] % n) & ((t[:, 0] >= n) == (t[:, 1] >= n))
+        return float((torch.where(diag, r * (c + 1) / 2, r * c)).sum())
+
     out = {}
-
-    def add(name, ms):
-        out[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "flop": flop}
-
+    bwd_flop = 4.0 * nl * n * D_FEAT
     Wg = eng.Wg if not eng.bf3 else torch.zeros(nl, 2 * n, device=eng.Z.device)
     # the fp32 kernels work on 64-wide tiles: their own table when the engine runs the 128-wide bf16x3 Gram
-    tiles64 = eng.tiles if eng.gram_tile == 64 else ops.build_tiles(n, 1, eng.rank, eng.world, device=eng.Z.device)
-    part64 = torch.zeros(tiles64.shape[0], 4, device=eng.Z.device)
-    # the Gram launch as the step issues it: XY and YY tiles only when the X-X tiles run in another launch (trainer.py); its
-    # algorithmic flop = the pairs it covers x 2 d: n^2 (XY) + n (n + 1) / 2 (YY upper triangle); row-sharded: 2 nl n
-    pairs = (n * n + n * (n + 1) / 2) if eng.world == 1 else 2.0 * nl * n
-    split = eng.n_main < eng.tiles.shape[0]   # some X-X tiles run in another launch (trainer.py: the M_4 launch carries them)
-    # the Gram launch holds every XY / YY tile and as many X-X tiles as it has free slots for; the late X-X tiles' share of the
-    # X-X block's algorithmic flop goes with them
-    slots = (eng.tiles[:, 4] & 3).cpu()
-    xx_total, xx_late = int((slots == 0).sum()), int((slots[eng.n_main:] == 0).sum())
-    late_flop = (flop - 2.0 * D_FEAT * pairs) * xx_late / max(xx_total, 1)
-    main_flop = flop - late_flop if split else flop
-    if eng.gram_tile == 64 and split:
-        tiles64 = eng.tiles[:eng.n_main]
-    ms = time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, tiles64, False, Wg, n + lo, part64))
-    out["mmd_gram_kernel<4,false,1>"] = {"ms": ms, "tflops": (main_flop if eng.gram_tile == 64 else flop) / (ms * 1e-3) / 1e12,
-                                         "flop": main_flop if eng.gram_tile == 64 else flop, "tiles": int(tiles64.shape[0])}
-    add("mmd_backward_kernel<4,2>", time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU,
-                                                                             mul_shift=eng.center)))
+    if eng.gram_tile == 64:
+        t64 = eng.tiles[:eng.n_main] if not eng.front_sharded else eng.tiles
+        flop64 = 2.0 * D_FEAT * pairs_of(tl[:t64.shape[0]])
+    else:
+        t64 = ops.build_tiles(n, 1, eng.rank, eng.world, device=eng.Z.device)
+        flop64 = 2.0 * D_FEAT * pairs_of(tl)
+    part64 = torch.zeros(t64.shape[0], 4, device=eng.Z.device)
+    ms = time_kernel(lambda: ops.mmd_gram(eng.Z, eng.sqn, n, p, eng.bw, t64, False, Wg, n + lo, part64), iters)
+    out["mmd_gram_kernel<4,false,1>"] = {"ms": ms, "tflops": flop64 / (ms * 1e-3) / 1e12, "flop": flop64, "tiles": int(t64.shape[0])}
+    ms = time_kernel(lambda: ops.mmd_backward(Wg, eng.Z, n + lo, nl, 2 * n, p, eng.Z[lo:lo + nl], eng.gU, mul_shift=eng.center), iters)
+    out["mmd_backward_kernel<4,2>"] = {"ms": ms, "tflops": bwd_flop / (ms * 1e-3) / 1e12, "flop": bwd_flop}
     if eng.bf3:
         gs = nl * eng.dp
         gname = "mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"
-        # as the step launches it (see above): the XY and YY tiles when the X-X tiles ride in the M_4 launch
-        ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[:eng.n_main], eng.Wh, eng.Wl, n + lo, eng.partial,
-                                                  tile=eng.gram_tile))
-        out[gname] = {"ms": ms, "tflops": main_flop / (ms * 1e-3) / 1e12, "flop": main_flop, "tiles": int(eng.n_main)}
-        if split:
-            xx_flop = late_flop
-            ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[eng.n_main:], None, None, 0,
-                                                      eng.partial[eng.n_main:], tile=eng.gram_tile))
+        # as the step launches it: one launch of the first n_main tiles (every XY / YY tile and as many X-X tiles as the launch has
+        # free slots for; the late X-X tiles ride in another launch) -- or, sharded front, the whole table in two launches
+        nt = eng.tiles.shape[0] if eng.front_sharded else eng.n_main
+        main_flop = 2.0 * D_FEAT * pairs_of(tl[:nt])
+        ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[:nt], eng.Wh, eng.Wl, n + lo, eng.partial,
+                                                  tile=eng.gram_tile), iters)
+        out[gname] = {"ms": ms, "tflops": main_flop / (ms * 1e-3) / 1e12, "flop": main_flop, "tiles": int(nt)}
+        if nt < eng.tiles.shape[0]:
+            xx_flop = 2.0 * D_FEAT * pairs_of(tl[nt:])
+            ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[nt:], None, None, 0,
+                                                      eng.partial[nt:], tile=eng.gram_tile), iters)
             out[gname + " [X-X tiles alone]"] = {"ms": ms, "tflops": xx_flop / (ms * 1e-3) / 1e12, "flop": xx_flop,
-                                                        "tiles": int(eng.tiles.shape[0] - eng.n_main)}
+                                                        "tiles": int(eng.tiles.shape[0] - nt)}
         big_bwd = ops.mmd_backward_bf3_tile(nl, d, eng.bsplits, eng.bwd_tile) == 128  # the library's own choice
         bname = "mmd_backward_bf3_big_kernel" if big_bwd else "mmd_backward_bf3_kernel<64>"
         if eng.rm_backward:  # B operand = the Gram's row-major images (transposed LDS reads)
-            add(bname, time_kernel(lambda: ops.mmd_backward_bf3_rm(eng.Wh, eng.Wl, eng.Zh, eng.Zl, 2 * n, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl],
-                                                                     eng.gU, eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile)))
+            ms = time_kernel(lambda: ops.mmd_backward_bf3_rm(eng.Wh, eng.Wl, eng.Zh, eng.Zl, 2 * n, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl],
+                                                             eng.gU, eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile), iters)
         else:
-            add(bname, time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl], eng.gU,
-                                                                  eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile)))
-        out["bf3_prepare_kernel"] = {"ms": time_kernel(lambda: ops.mmd_bf3_prepare(eng.Z, 2 * n, d, eng.Zh, eng.Zl, eng.ZTh, eng.ZTl))}
+            ms = time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl], eng.gU,
+                                                          eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile), iters)
+        out[bname] = {"ms": ms, "tflops": bwd_flop / (ms * 1e-3) / 1e12, "flop": bwd_flop}
+        out["bf3_prepare_kernel"] = {"ms": time_kernel(lambda: ops.mmd_bf3_prepare(eng.Z, 2 * n, d, eng.Zh, eng.Zl, eng.ZTh, eng.ZTl), iters)}
     return out
 
 
@@ -203,7 +232,7 @@ def cpu_baseline(data, params, seconds):
 
 
 def gpu_first_loss(params, X, z, **engine_kw):
-    """Loss of the first step on the same params / batch / noise as the CPU probe."""
+    """Loss of the first step on the same params / batch / noise as the CPU probe (an unsharded engine on this rank's GPU)."""
     import vgan_amd
     from vgan_amd.ops import HipOps
     from vgan_amd.trainer import NoKLStepEngine
@@ -307,16 +336,67 @@ def bench_kl(args):
     print(json.dumps(out), flush=True)
 
 
+def traffic_of(kernel, world):
+    """HBM-side bytes per launch of `kernel` from the COMMITTED PMC passes (profiles/traffic*.json, regenerated by
+    tools/pmc_traffic.py under rocprofv3 --pmc: counters cannot be collected inside this timing run)."""
+    name = {"c3": "traffic.json", "c4": "traffic_c4.json", "c5": "traffic_c5.json"}.get(CONFIG)
+    if name is None or world != 1:
+        return None, None
+    tp = os.path.join(ROOT, "profiles", name)
+    try:
+        v = json.load(open(tp)).get(kernel.split("<")[0].split(" ")[0], {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None, None
+    return v, (f"profiles/{name}: committed rocprofv3 --pmc pass (tools/pmc_traffic.py on tools/kbench.py), not measured in this run"
+               if v is not None else None)
+
+
+def roofline_of(e, kern, steps_per_s, world):
+    """The roofline block: the LONGEST of the two MMD contractions of the active precision mode is the dominant kernel."""
+    if e.bf3:
+        # The kernels issue v_mfma_f32_32x32x16_bf16; `achieved` is ALGORITHMIC flops / launch time as the contract says,
+        # `peak` the dense bf16 MFMA rate.  Each algorithmic product costs three bf16 products (hi.hi' + hi.lo' + lo.hi'),
+        # so the executed MFMA rate is 3x `achieved`; both fractions are reported.
+        peak = BF16_MFMA_PEAK_TFLOPS
+        cands = [k for k in kern if "bf3" in k and "tflops" in kern[k] and "alone" not in k]
+    else:
+        peak = FP32_MFMA_PEAK_TFLOPS
+        cands = [k for k in kern if "bf3" not in k and "tflops" in kern[k]]
+    name = max(cands, key=lambda k: kern[k]["ms"])
+    g = kern[name]
+    extra = {}
+    if e.bf3:
+        extra = {"executed_mfma_tflops": 3.0 * g["tflops"], "executed_frac": 3.0 * g["tflops"] / peak,
+                 "vs_fp32_mfma_peak": g["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                 "note": "fp32-accurate contraction on the bf16 MFMA via a 3-way operand split; the fp32-MFMA kernels of the same "
+                         "contractions are timed as a whole step in 'fp32_mode'"}
+    also = {}
+    for k, v in kern.items():
+        if k == name:
+            continue
+        if "tflops" not in v:
+            also[k] = {"avg_launch_ms": v["ms"], "bound": "hbm"}
+            continue
+        pk = BF16_MFMA_PEAK_TFLOPS if "bf3" in k else FP32_MFMA_PEAK_TFLOPS
+        tr, _ = traffic_of(k, world)
+        also[k] = {"achieved": v["tflops"], "peak": pk, "frac": v["tflops"] / pk, "avg_launch_ms": v["ms"],
+                   "algorithmic_flop_per_launch": v["flop"], "traffic": tr}
+        if "bf3" in k:
+            also[k]["executed_frac"] = 3.0 * v["tflops"] / pk
+    step_flop = 8.0 * N_BATCH * N_BATCH * D_FEAT + 6.0 * N_BATCH * e.fp.total
+    tr, src = traffic_of(name, world)
+    return {"bound": "mfma", "kernel": name, "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
+            "frac": g["tflops"] / peak, "traffic": tr, "traffic_source": src,
+            "avg_launch_ms": g["ms"], "algorithmic_flop_per_launch": g["flop"], **extra, "also": also,
+            "step_tflops": step_flop * steps_per_s / world / 1e12,
+            "step_frac_of_fp32_mfma_peak": step_flop * steps_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+
+
 def main():
-    global N_BATCH, D_FEAT, EPOCH_BATCHES, CONFIG, WORKLOAD
     args = parse()
-    CONFIG = args.workload
-    N_BATCH, D_FEAT, EPOCH_BATCHES, WORKLOAD = WORKLOADS[CONFIG]
+    select_workload(args.workload)
     if args.path == "kl":
         return bench_kl(args)
-    if CONFIG in ("c4", "c5"):
-        args.steps, args.warmup = min(args.steps, 200), min(args.warmup, 8)
-        args.no_cpu_baseline = args.no_cpu_baseline or CONFIG == "c5"  # N = 16384: ~17 GB and ~15 s per CPU step
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -340,7 +420,7 @@ def main():
             dist.init_process_group(backend)
 
     torch.manual_seed(1234)
-    use_graph = not args.no_graph and backend == "nccl"
+    graph_ok = [not args.no_graph and backend == "nccl"]
 
     def prewarm(e):
         # every rank must run the SAME number of steps (each one holds a collective and draws the shared shuffles): rank 0
@@ -355,129 +435,139 @@ def main():
             run_steps(e, EPOCH_BATCHES, (it + 1) * EPOCH_BATCHES)
         torch.cuda.synchronize()
 
-    def timed_leg(**ekw):
-        """Build an engine, pre-warm, W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize on both
-        sides; max over ranks.  Returns (engine, seconds, graph used, mean loss of the timed steps)."""
-        nonlocal use_graph
-        eng, data, params = build_engine(rank, world, use_graph, **ekw)
-        try:
-            prewarm(eng)
-            run_steps(eng, args.warmup, 0)
+    def timed_leg(steps, warmup, **ekw):
+        """Build an engine, pre-warm, W warm-up steps, one untimed block of K steps (captures every graph the block replays),
+        then `repeats` blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides, MAX over ranks.
+        Returns (engine, data, params, per-block seconds, mean loss of the timed steps)."""
+        def warm():
+            e, data, params = build_engine(rank, world, graph_ok[0], **ekw)
+            prewarm(e)
+            run_steps(e, warmup, 0)
+            run_steps(e, steps, 0)
             torch.cuda.synchronize()
+            return e, data, params
+        try:
+            eng, data, params = warm()
         except Exception as e:  # a collective that cannot be captured: fall back to eager launches (same process)
-            if not use_graph:
+            if not graph_ok[0]:
                 raise
             print(f"[bench] HIP-graph path failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
-            use_graph = False
-            eng, data, params = build_engine(rank, world, False, **ekw)
-            prewarm(eng)
-            run_steps(eng, args.warmup, 0)
-            torch.cuda.synchronize()
+            graph_ok[0] = False
+            eng, data, params = warm()
         eng.epoch_loss()
-        eng.first_timed_step = eng.steps_done  # training steps already taken: `mean_loss` below is the mean over the NEXT K steps
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(eng, args.steps, args.warmup)
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        mean_loss = eng.epoch_loss() * EPOCH_BATCHES / max(args.steps, 1)
-        return eng, data, params, elapsed, mean_loss
+        eng.first_timed_step = eng.steps_done  # training steps already taken: `mean_loss` is the mean over the timed steps
+        blocks = []
+        for _ in range(max(1, args.repeats)):
+            if dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(eng, steps, 0)
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            if dist:
+                t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            blocks.append(elapsed)
+        mean_loss = eng.epoch_loss() * EPOCH_BATCHES / max(steps * len(blocks), 1)
+        return eng, data, params, blocks, mean_loss
 
-    ekw = {"mmd_precision": args.precision} if args.precision else {}
-    eng, data, params, elapsed, mean_loss = timed_leg(**ekw)
+    def rates(blocks, steps):
+        med = sorted(blocks)[len(blocks) // 2]
+        return {"value": steps / med, "ms_per_step": 1e3 * med / steps, "steps": steps, "repeats": len(blocks),
+                "repeat_steps_per_s": [steps / b for b in blocks], "min": steps / max(blocks), "max": steps / min(blocks)}
+
+    steps, warmup = args.steps, args.warmup
+    if CONFIG in ("c4", "c5"):
+        steps, warmup = min(steps, 200), min(warmup, 8)
+        args.no_cpu_baseline = args.no_cpu_baseline or CONFIG == "c5"  # N = 16384: ~17 GB and ~15 s per CPU step
+    ekw = {}
+    if args.precision:
+        ekw["mmd_precision"] = args.precision
+    if args.front:
+        ekw["front"] = args.front
+    eng, data, params, blocks, mean_loss = timed_leg(steps, warmup, **ekw)
+    main_rate = rates(blocks, steps)
     kern = kernel_rooflines(eng)
-    step_flop = 8.0 * N_BATCH * N_BATCH * D_FEAT + 6.0 * N_BATCH * eng.fp.total
-
-    def traffic_of(kernel):
-        """HBM-side bytes per launch of `kernel` from the COMMITTED PMC pass (profiles/traffic.json, regenerated by
-        `python tools/pmc_traffic.py` under rocprofv3 --pmc: counters cannot be collected inside this timing run)."""
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if not (os.path.exists(tp) and world == 1 and CONFIG == "c3"):
-            return None
-        try:
-            return json.load(open(tp)).get(kernel, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-
-    def roofline_of(e, kern, steps_per_s):
-        if e.bf3:
-            # The dominant kernel issues v_mfma_f32_32x32x16_bf16; `achieved` is ALGORITHMIC flops / launch time as the
-            # contract says, `peak` the dense bf16 MFMA rate.  Each algorithmic product costs three bf16 products
-            # (hi.hi' + hi.lo' + lo.hi'), so the executed MFMA rate is 3x `achieved`; both fractions are reported.
-            name, peak = ("mmd_gram_bf3_big_kernel" if e.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"), BF16_MFMA_PEAK_TFLOPS
-            g = kern[name]
-            extra = {"executed_mfma_tflops": 3.0 * g["tflops"], "executed_frac": 3.0 * g["tflops"] / peak,
-                     "vs_fp32_mfma_peak": g["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                     "note": "fp32-accurate Gram on the bf16 MFMA via a 3-way operand split; the fp32-MFMA kernels of the same "
-                             "contraction are timed as a whole step in 'fp32_mode'"}
-        else:
-            name, peak = "mmd_gram_kernel<4,false,1>", FP32_MFMA_PEAK_TFLOPS
-            g = kern[name]
-            extra = {}
-        also = {}
-        for k, v in kern.items():
-            if k == name or "tflops" not in v:
-                continue
-            pk = BF16_MFMA_PEAK_TFLOPS if "bf3" in k else FP32_MFMA_PEAK_TFLOPS
-            also[k] = {"achieved": v["tflops"], "peak": pk, "frac": v["tflops"] / pk, "avg_launch_ms": v["ms"]}
-        if "bf3_prepare_kernel" in kern:
-            also["bf3_prepare_kernel"] = {"avg_launch_ms": kern["bf3_prepare_kernel"]["ms"], "bound": "hbm"}
-        tr = traffic_of(name.split("<")[0])
-        return {"bound": "mfma", "kernel": name, "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
-                "frac": g["tflops"] / peak, "traffic": tr,
-                "traffic_source": ("profiles/traffic.json: committed rocprofv3 --pmc pass (tools/pmc_traffic.py), not measured "
-                                   "in this run") if tr is not None else None,
-                "avg_launch_ms": g["ms"], "algorithmic_flop_per_launch": g["flop"], **extra, "also": also,
-                "step_tflops": step_flop * steps_per_s / world / 1e12,
-                "step_frac_of_fp32_mfma_peak": step_flop * steps_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+    main_cfg = {"workload": WORKLOAD, "global_batch": N_BATCH, "features": D_FEAT, "latent": eng.L,
+                "rows_per_gpu": eng.nl, "parallelism": f"dp{world} (row-sharded Gram, {'sharded' if eng.front_sharded else 'replicated'} front)",
+                "hip_graph": bool(graph_ok[0] and eng.use_graph), "mean_loss": mean_loss, "first_timed_step": eng.first_timed_step,
+                "prewarm_s": args.prewarm_seconds, "generator": eng.mode, "chain_association": "flops" if eng.chain_flops else "depth",
+                "mmd_precision": eng.precision, "gram_tile": eng.gram_tile, "timed_blocks": len(blocks)}
+    main_roof = roofline_of(eng, kern, main_rate["value"], world)
+    main_bf3, main_precision = eng.bf3, eng.precision
+    del eng
+    torch.cuda.empty_cache()
 
     # The reference's own arithmetic is fp32 end to end.  When the engine's choice is the split-bf16 mode, the SAME
     # workload is timed a second time with the fp32-MFMA kernels (same warm-up discipline, same step count), so that the
     # driver's line carries a step rate for both arithmetic modes.
     fp32_block = None
-    if eng.bf3:
-        e32, _, _, el32, ml32 = timed_leg(mmd_precision="fp32")
-        k32 = kernel_rooflines(e32)
-        fp32_block = {"value": args.steps / el32, "unit": "steps/s", "ms_per_step": 1e3 * el32 / args.steps, "steps": args.steps,
-                      "warmup": args.warmup, "mmd_precision": "fp32", "mean_loss": ml32, "first_timed_step": e32.first_timed_step, "dtype": "f32 (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
-                      "roofline": roofline_of(e32, k32, args.steps / el32)}
+    if main_bf3:
+        e32, _, _, b32, ml32 = timed_leg(steps, warmup, **{**ekw, "mmd_precision": "fp32"})
+        r32 = rates(b32, steps)
+        fp32_block = {**r32, "unit": "steps/s", "warmup": warmup, "mmd_precision": "fp32", "mean_loss": ml32,
+                      "first_timed_step": e32.first_timed_step, "dtype": "f32 (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
+                      "roofline": roofline_of(e32, kernel_rooflines(e32), r32["value"], world)}
         del e32
         torch.cuda.empty_cache()
 
+    # ---- the larger BASELINE.json configurations and the alternative exchange schedules, in the same invocation ----------
+    extra = {}
+    if CONFIG == "c3" and not args.no_extra and not args.precision and not args.front:
+        legs = []
+        if world > 1:
+            legs.append(("c3_overlapped_allreduce", "c3", dict(overlap_exchange=True)))
+        legs.append(("c4", "c4", {}))
+        if world > 1:
+            legs.append(("c4_replicated_front", "c4", dict(front="replicated")))
+        legs.append(("c5_fp32", "c5", dict(mmd_precision="fp32")))
+        if world > 1:
+            legs.append(("c5_fp32_replicated_front", "c5", dict(mmd_precision="fp32", front="replicated")))
+        legs.append(("c5_bf16x3", "c5", {}))
+        if world > 1:
+            legs.append(("c5_bf16x3_replicated_front", "c5", dict(front="replicated")))
+        for name, cfg, kw in legs:
+            select_workload(cfg)
+            k, w = (steps, warmup) if cfg == "c3" else (min(steps, 40 if cfg == "c4" else 16), min(warmup, 8))
+            e, _, _, b, ml = timed_leg(k, w, **kw)
+            extra[name] = {"workload": WORKLOAD, **rates(b, k), "unit": "steps/s", "warmup": w, "n_gpus": world, "scaling": "strong",
+                           "global_batch": N_BATCH, "features": D_FEAT, "rows_per_gpu": e.nl, "mmd_precision": e.precision,
+                           "front": "sharded" if e.front_sharded else "replicated", "overlapped_allreduce": bool(e.overlap),
+                           "chain_association": "flops" if e.chain_flops else "depth", "gram_tile": e.gram_tile,
+                           "hip_graph": bool(graph_ok[0] and e.use_graph), "mean_loss": ml}
+            del e
+            torch.cuda.empty_cache()
+        select_workload(args.workload)
+
     if rank == 0:
-        steps_per_s = args.steps / elapsed
         out = {
-            "metric": f"V-GAN train steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": steps_per_s, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": f"V-GAN train steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": main_rate["value"], "unit": "steps/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": main_rate["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": ("f32; MMD contractions of `value`: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (centred operand); "
-                      "the same step with the fp32 MFMA is timed in `fp32_mode`") if eng.bf3 else "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "global_batch": N_BATCH, "features": D_FEAT, "latent": eng.L,
-                       "rows_per_gpu": eng.nl, "parallelism": f"dp{world} (row-sharded Gram, replicated generator)",
-                       "hip_graph": bool(use_graph), "mean_loss": mean_loss, "first_timed_step": eng.first_timed_step, "prewarm_s": args.prewarm_seconds,
-                       "generator": eng.mode, "mmd_precision": eng.precision, "gram_tile": eng.gram_tile},
+                      "the same step with the fp32 MFMA is timed in `fp32_mode`") if main_bf3 else "f32", "data": "synthetic",
+            "config": main_cfg, "repeat_steps_per_s": main_rate["repeat_steps_per_s"],
+            "timing": f"median of {main_rate['repeats']} blocks of {steps} steps, each bracketed by barrier + synchronize, max over ranks",
         }
-        out["roofline"] = roofline_of(eng, kern, steps_per_s)
+        out["roofline"] = main_roof
         if fp32_block is not None:
             out["fp32_mode"] = fp32_block
-        if world == 1 and not args.no_cpu_baseline:
+        if extra:
+            out["extra"] = extra
+        if not args.no_cpu_baseline:  # rank 0, whatever N: the other ranks wait at the closing barrier
             cb, cpu_loss, (X, z) = cpu_baseline(data, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
-            gl = gpu_first_loss(params, X, z, mmd_precision=eng.precision)
-            out["parity"] = {"mmd_precision": eng.precision, "loss_gpu": gl, "loss_cpu_port": cpu_loss, "abs_diff": abs(gl - cpu_loss), "bar": 1e-4}
-            if eng.bf3:
+            gl = gpu_first_loss(params, X, z, mmd_precision=main_precision)
+            out["parity"] = {"mmd_precision": main_precision, "loss_gpu": gl, "loss_cpu_port": cpu_loss, "abs_diff": abs(gl - cpu_loss), "bar": 1e-4}
+            if main_bf3:
                 g32 = gpu_first_loss(params, X, z, mmd_precision="fp32")
                 out["parity"]["fp32_mode"] = {"loss_gpu": g32, "abs_diff": abs(g32 - cpu_loss)}
-            out["speedup_vs_cpu"] = steps_per_s / cb["value"]
+            out["speedup_vs_cpu"] = main_rate["value"] / cb["value"]
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

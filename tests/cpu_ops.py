@@ -25,12 +25,12 @@ class CpuOps:
     def __init__(self):
         self.lib = _lib.load()  # host-side helpers of the .so (tile tables) work without a GPU
 
-    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64, split_xx=False):
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64, split_xx=False, split=None):
         flat, cnt = _lib.build_tiles(n, grad_mode, rank, world, tile)
         table = torch.tensor(flat, dtype=torch.int32).view(cnt, 8)
-        if split_xx:
-            main, xx = _lib.split_tiles(table, tile)
-            return torch.cat([main, xx]), main.shape[0]
+        if split_xx or split:
+            first, second = _lib.split_tiles(table, tile, yy_last=(split == "yy_last"))
+            return torch.cat([first, second]), first.shape[0]
         return table
 
     def colmax_chunks(self, n):

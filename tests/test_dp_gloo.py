@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, steps, out_dir, mode, overlap=None):
+def _worker(rank, world, port, steps, out_dir, mode, overlap=None, front=None, precision=None, assoc=None):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,8 +30,11 @@ def _worker(rank, world, port, steps, out_dir, mode, overlap=None):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = load_golden("f3_traj_c1.npz")
     eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["data"], 128, 10, rank=rank, world=world, generator_mode=mode,
-                         lr=float(g["lr"]), weight_decay=float(g["weight_decay"]), overlap_exchange=overlap)
+                         lr=float(g["lr"]), weight_decay=float(g["weight_decay"]), overlap_exchange=overlap, front=front,
+                         mmd_precision=precision, chain_assoc=assoc)
     assert eng.overlap == (False if overlap is None else overlap)  # the plain schedule is the default (measured faster)
+    assert eng.front_sharded == (front == "sharded")               # at this size "auto" keeps the replicated front
+    assert eng.chain_flops == (assoc == "flops")
     losses = []
     for t in range(steps):
         if t % 10 == 0:
@@ -64,6 +67,25 @@ def test_row_sharded_dp_matches_single_process(world, mode, tmp_path):
         np.testing.assert_allclose(o["bw"], float(g["bw"]), rtol=1e-5)
         assert abs(float(o["epoch_mean"]) - g["losses"][steps:steps + 10].mean()) < 2e-5
         assert np.array_equal(o["flat"], outs[0]["flat"])              # replicas stay bit-identical
+
+
+@pytest.mark.parametrize("world,precision,assoc", [(2, "fp32", None), (4, "fp32", "flops"), (2, "bf16x3", None), (4, "bf16x3", None)])
+def test_sharded_front_matches_single_process(world, precision, assoc, tmp_path):
+    """front='sharded' (every rank runs generator forward, mask / projection and operand split for ITS
+    n/G rows and the ranks all-gather the Y rows, their norms and the column arg-max keys; X-X triangle dealt round-robin,
+    mirrored stores inside a rank's diagonal YY block at world 2, unaligned row blocks at world 4): the same statistic as the
+    unsharded reference run, step by step and in the epoch mean, replicas bit-identical -- in both precision modes and with
+    the flop-minimal chain association."""
+    steps = 20
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), "collapsed", None, "sharded", precision, assoc), nprocs=world,
+             join=True)
+    g = load_golden("f3_traj_c1.npz")
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for o in outs:
+        assert np.abs(o["losses"] - g["losses"][:steps]).max() < 2e-5
+        np.testing.assert_allclose(o["bw"], float(g["bw"]), rtol=1e-5)
+        assert abs(float(o["epoch_mean"]) - g["losses"][steps:steps + 10].mean()) < 2e-5
+        assert np.array_equal(o["flat"], outs[0]["flat"])
 
 
 def test_overlapped_exchange_schedule_equals_plain_schedule(tmp_path):

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, steps, out_dir, precision, n, d_case):
+def _run(rank, world, port, steps, out_dir, precision, n, d_case, front=None):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,9 +42,9 @@ def _run(rank, world, port, steps, out_dir, precision, n, d_case):
         noise = g["noise"][:steps]
         kw = dict(lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
     else:
-        d = 784
+        d = 784 if d_case == "c3" else 2048
         rng = np.random.default_rng(3)
-        data = orc.synthetic_dataset("c3", rows=4 * n)
+        data = orc.synthetic_dataset(d_case, rows=4 * n)
         params = orc.synthetic_generator_params(d)
         idx = np.stack([rng.permutation(4 * n)[:n] for _ in range(steps)])
         noise = rng.normal(size=(steps, n, orc.latent_size(d))).astype(np.float32)
@@ -55,7 +55,8 @@ def _run(rank, world, port, steps, out_dir, precision, n, d_case):
         for q, v in zip(gen.parameters(), params):
             q.copy_(torch.as_tensor(v))
     eng = NoKLStepEngine(HipOps(), gen.cuda(), torch.as_tensor(data).cuda(), n, 1, noise="host", use_graph=False, loss_accum_scale=1.0,
-                         rank=rank, world=world, mmd_precision=precision, **kw)
+                         rank=rank, world=world, mmd_precision=precision, front=front if world > 1 else None, **kw)
+    assert eng.front_sharded == (world > 1 and (front == "sharded" or (front is None and n * d >= (1 << 22))))
     losses = []
     for t in range(steps):
         eng.set_epoch_batches(torch.as_tensor(idx[t:t + 1]))
@@ -69,10 +70,15 @@ def _run(rank, world, port, steps, out_dir, precision, n, d_case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,n,precision,steps", [("c1", 128, "fp32", 12), ("c3", 1024, "bf16x3", 4), ("c3", 512, "fp32", 3)])
-def test_two_ranks_on_the_real_kernels(case, n, precision, steps, tmp_path):
-    mp.spawn(_run, args=(1, 0, steps, str(tmp_path), precision, n, case), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), steps, str(tmp_path), precision, n, case), nprocs=2, join=True)
+@pytest.mark.parametrize("case,n,precision,steps,front", [
+    ("c1", 128, "fp32", 12, "replicated"), ("c3", 1024, "bf16x3", 4, "replicated"), ("c3", 512, "fp32", 3, "replicated"),
+    # the sharded front (all-gather of the Y rows; trainer.py): small and metric-sized shapes forced, a c4-like shape
+    # (d = 2048 > 1024: unfused operand split, 128-wide tiles, flop-minimal chain) by the engine's own size rule
+    ("c1", 128, "fp32", 12, "sharded"), ("c3", 1024, "bf16x3", 4, "sharded"), ("c3", 512, "fp32", 3, "sharded"),
+    ("c4", 2048, "bf16x3", 3, None), ("c4", 2048, "fp32", 2, None)])
+def test_two_ranks_on_the_real_kernels(case, n, precision, steps, front, tmp_path):
+    mp.spawn(_run, args=(1, 0, steps, str(tmp_path), precision, n, case, front), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), steps, str(tmp_path), precision, n, case, front), nprocs=2, join=True)
     one = np.load(tmp_path / "w1_r0.npz")
     r0, r1 = np.load(tmp_path / "w2_r0.npz"), np.load(tmp_path / "w2_r1.npz")
     assert np.array_equal(r0["flat"], r1["flat"])                        # replicas stay bit-identical

@@ -28,8 +28,10 @@ def test_synthetic_inputs_identical_to_oracle_copy():
     from vgan_amd import synth
     for cfg, rows in [("c1", 300), ("c2", 200), ("c3", 64), ("c4", 8), ("c5", 4)]:
         assert np.array_equal(synth.synthetic_dataset(cfg, rows=rows), orc.synthetic_dataset(cfg, rows=rows))
-    for a, b in zip(synth.synthetic_generator_params(784), orc.synthetic_generator_params(784)):
-        assert np.array_equal(a, b)
+    for d in (20, 166, 784, 2048, 4096):  # c1 .. c5
+        assert synth.latent_size(d) == orc.latent_size(d)
+        for a, b in zip(synth.synthetic_generator_params(d), orc.synthetic_generator_params(d)):
+            assert np.array_equal(a, b)
 
 
 def make_engine(params, data, n, nb, **kw):
@@ -70,6 +72,24 @@ def test_engine_two_steps_vs_reference_fixture(cfg, mode):
             np.testing.assert_allclose(eng.grad_view(i).numpy(), ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-8))
             np.testing.assert_allclose(eng.fp.view(eng.fp.flat, i).numpy(), g[f"param{step + 1}_{i}"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(float(eng.bw), float(g["bw"]), rtol=1e-5)
+
+
+def test_engine_flop_minimal_chain_association_vs_reference_fixture():
+    """chain_assoc='flops' (At_k = Wt_k At_{k-1}, M_{k-1} = Wt_k^T M_k: what the engine picks once the suffix product B_3 passes
+    1 GFLOP, i.e. from c4 up) against the reference's two steps of fixture f2 (c2): same losses, gradients and parameters."""
+    g = load_golden("f2_step_c2.npz")
+    n = g["batch"].shape[0]
+    eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], g["batch"], n, 1, chain_assoc="flops")
+    assert eng.chain_flops
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    for step in range(2):
+        eng.set_noise(torch.as_tensor(g["noise"]))
+        eng.step()
+        assert abs(float(eng.loss) - float(g[f"loss{step}"])) < 2e-5
+        for i in range(8):
+            ref = g[f"grad{step}_{i}"]
+            np.testing.assert_allclose(eng.grad_view(i).numpy(), ref, rtol=0, atol=1e-3 * max(np.abs(ref).max(), 1e-8))
+            np.testing.assert_allclose(eng.fp.view(eng.fp.flat, i).numpy(), g[f"param{step + 1}_{i}"], rtol=0, atol=5e-6)
 
 
 def test_engine_fused_update_path_equals_separate_optimiser_launch():

@@ -70,10 +70,17 @@ def test_row_sharded_tables(n, world, tile):
     want[:n, n:] = 0
     assert np.array_equal(seen, want)          # union of the ranks = the whole matrix, no symmetry needed
     assert np.array_equal(writes[n:], np.ones((n, N))) and writes[:n].sum() == 0
-    for r, tab in enumerate(tabs):             # each rank only touches its own rows
+    for r, tab in enumerate(tabs):             # every gradient weight a rank writes is a row of its own (mirrored ones too)
         lo, hi = n * r // world, n * (r + 1) // world
-        rows = tab[:, 0] % n
+        grad = tab[(tab[:, 4] & SLOT) != 0]
+        rows = grad[:, 0] - n
         assert ((rows >= lo) & (rows < hi)).all()
+        mir = grad[(grad[:, 4] & MIRROR) != 0]
+        assert ((mir[:, 1] - n >= lo) & (mir[:, 1] - n < hi)).all()
+    # the X-X block (sums only) is shared out as its upper triangle: balanced to one tile, half the pairs of "rows x all"
+    xx = [int(((t[:, 4] & SLOT) == 0).sum()) for t in tabs]
+    nt = (n + tile - 1) // tile
+    assert sum(xx) == nt * (nt + 1) // 2 and max(xx) - min(xx) <= 1
 
 
 def test_bad_arguments():

@@ -9,6 +9,8 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <string>
+
 #include "vgan_common.hpp"
 
 namespace {
@@ -19,8 +21,10 @@ struct Rccl {
     ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
     ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*error_string)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why;  // dlerror() text captured at the failing dlopen / dlsym (a later dl* call would have wiped it)
 };
 
 Rccl& rccl() {
@@ -28,14 +32,26 @@ Rccl& rccl() {
         Rccl q;
         q.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (q.handle == nullptr) q.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (q.handle != nullptr) {
-            q.get_unique_id = reinterpret_cast<decltype(q.get_unique_id)>(dlsym(q.handle, "ncclGetUniqueId"));
-            q.comm_init_rank = reinterpret_cast<decltype(q.comm_init_rank)>(dlsym(q.handle, "ncclCommInitRank"));
-            q.comm_destroy = reinterpret_cast<decltype(q.comm_destroy)>(dlsym(q.handle, "ncclCommDestroy"));
-            q.all_reduce = reinterpret_cast<decltype(q.all_reduce)>(dlsym(q.handle, "ncclAllReduce"));
-            q.error_string = reinterpret_cast<decltype(q.error_string)>(dlsym(q.handle, "ncclGetErrorString"));
-            q.ok = q.get_unique_id && q.comm_init_rank && q.comm_destroy && q.all_reduce && q.error_string;
+        if (q.handle == nullptr) {
+            const char* e = dlerror();
+            q.why = e ? e : "dlopen failed";
+            return q;
         }
+        auto sym = [&q](const char* name) -> void* {
+            void* p = dlsym(q.handle, name);
+            if (p == nullptr && q.why.empty()) {
+                const char* e = dlerror();
+                q.why = e ? e : (std::string("missing symbol ") + name);
+            }
+            return p;
+        };
+        q.get_unique_id = reinterpret_cast<decltype(q.get_unique_id)>(sym("ncclGetUniqueId"));
+        q.comm_init_rank = reinterpret_cast<decltype(q.comm_init_rank)>(sym("ncclCommInitRank"));
+        q.comm_destroy = reinterpret_cast<decltype(q.comm_destroy)>(sym("ncclCommDestroy"));
+        q.all_reduce = reinterpret_cast<decltype(q.all_reduce)>(sym("ncclAllReduce"));
+        q.all_gather = reinterpret_cast<decltype(q.all_gather)>(sym("ncclAllGather"));
+        q.error_string = reinterpret_cast<decltype(q.error_string)>(sym("ncclGetErrorString"));
+        q.ok = q.get_unique_id && q.comm_init_rank && q.comm_destroy && q.all_reduce && q.all_gather && q.error_string;
         return q;
     }();
     return r;
@@ -56,7 +72,7 @@ struct vgan_dp_comm {
 #define VGAN_NEED_RCCL()                                                                      \
     do {                                                                                      \
         if (!rccl().ok) {                                                                     \
-            ::vgan::set_error("RCCL is not available (librccl.so could not be opened): %s", dlerror() ? dlerror() : "missing symbol"); \
+            ::vgan::set_error("RCCL is not available (librccl.so): %s", rccl().why.c_str());    \
             return VGAN_ERR_HIP;                                                              \
         }                                                                                     \
     } while (0)

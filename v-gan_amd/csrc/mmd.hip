@@ -400,12 +400,26 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
             return -1;
         }
         const int lo = (int)((long)n * rank / world), hi = (int)((long)n * (rank + 1) / world);
-        for (int r = lo; r < hi; r += T)
-            for (int c = 0; c < n; c += T) emit(r, c, hi, n, 0);  // XX rows (sums only)
+        // XX feeds only the block sum of the reported loss (no gradient weights, so no row ownership): the upper triangle of
+        // the WHOLE block is dealt round-robin over the ranks -- n^2 / (2 world) pairs each instead of the n^2 / world of
+        // "own rows x all columns".
+        int k = 0;
+        for (int r = 0; r < n; r += T)
+            for (int c = r; c < n; c += T, ++k)
+                if (k % world == rank) emit(r, c, n, n, 0 | (c > r ? VGAN_TF_TWICE : 0));
         for (int r = lo; r < hi; r += T)
             for (int c = 0; c < n; c += T) emit(n + r, c, n + hi, n, 1 | VGAN_TF_NEG | (grad_mode ? VGAN_TF_STORE : 0));
+        // YY: own rows x all columns; inside the rank's own diagonal block the upper triangle with mirrored stores does (both
+        // halves of a mirrored pair are rows of this rank), when the block is a whole number of tiles on the tile grid
+        const bool tri = lo % T == 0 && hi % T == 0;
         for (int r = lo; r < hi; r += T)
-            for (int c = 0; c < n; c += T) emit(n + r, n + c, n + hi, 2 * n, 2 | (grad_mode ? VGAN_TF_STORE : 0));
+            for (int c = 0; c < n; c += T) {
+                const bool diag = tri && c >= lo && c < hi;
+                if (diag && c < r) continue;
+                int fl = 2 | (grad_mode ? VGAN_TF_STORE : 0);
+                if (diag && c > r) fl |= VGAN_TF_TWICE | (grad_mode ? VGAN_TF_MIRROR : 0);
+                emit(n + r, n + c, n + hi, 2 * n, fl);
+            }
     }
     if (out != nullptr && count > cap) return -1;
     if (out != nullptr) order_tiles_for_xcds(out, count, T);

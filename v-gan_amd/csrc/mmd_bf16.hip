@@ -8,8 +8,11 @@
 // MFMA time.  The C/D fragment layout of the MFMA does not depend on the input type, so the fused epilogues (distance,
 // exp, squaring chain, block sums, gradient weights) are the fp32 kernels' code, character for character.
 //
-// Operands are prepared once per step by vgan_mmd_bf3_prepare: Z -> (Zh, Zl) row-major for the Gram and (ZTh, ZTl),
-// the transposed copy, for the backward product, whose B fragment needs 8 consecutive k (= Z rows) per lane.
+// Operands are prepared once per step (inside the mask / projection launch, rows.hip: mask_forward_bf3_kernel, or by
+// vgan_mmd_bf3_prepare where that kernel's shape contract does not hold): Z -> (Zh, Zl), ROW-MAJOR split images that BOTH
+// contractions read -- the Gram directly, the backward product W . Z through transposed LDS reads (ds_read_b64_tr_b16,
+// GemmBF3::run_bt), which hand each lane the 8 consecutive k (= Z rows) its B fragment needs.  The transposed copies
+// (ZTh, ZTl) of round 1 are written only on request (vgan_mmd_backward_bf3, kept for measurement).
 #include "gemm_bf3.hpp"
 #include "mmd_common.hpp"
 #include "mmd_xx.hpp"

@@ -217,22 +217,38 @@ class KLStepEngine:
         generator-phase step."""
         m = self.steps_per_graph
         while count > 0:
-            if not self.use_graph or not self.has_bw:
+            if not self.use_graph or not self.has_bw or self.graphs.get(key) is False:
                 body()
                 count -= 1
                 continue
-            block = m if (count >= m and m > 1 and self.noise_mode == "device" and key in self.graphs) else 1
-            gkey = (key, block)
-            g = self.graphs.get(gkey if block > 1 else key)
+            block = m if (count >= m and m > 1 and self.noise_mode == "device" and key in self.graphs and
+                          self.graphs.get((key, m)) is not False) else 1
+            gkey = (key, block) if block > 1 else key
+            g = self.graphs.get(gkey)
             if g is None:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for _ in range(block):
-                        body()
-                self.graphs[gkey if block > 1 else key] = g
+                g = self.graphs[gkey] = self._capture(body, block)
+                if g is False:  # no graph of this size: the one-step graph (block > 1) or eager launches (block == 1) take over
+                    continue
             g.replay()
             count -= block
+
+    @staticmethod
+    def _capture(body, steps):
+        """`steps` step bodies captured into one HIP graph, or False if the capture fails: like NoKLStepEngine._capture_graph,
+        a failed capture means "no graph of this size", never "no training" -- the caller falls back in the same process."""
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                for _ in range(steps):
+                    body()
+        except Exception as e:  # noqa: BLE001
+            import warnings
+            warnings.warn(f"vgan_amd: HIP-graph capture of {steps} VGAN.fit step(s) failed ({type(e).__name__}: {e}); "
+                          f"falling back to {'the one-step graph' if steps > 1 else 'eager launches'}")
+            torch.cuda.synchronize()
+            return False
+        return g  # capture does not execute: the caller replays it
 
     def _finalize_job(self, tiles):
         return self.ops.finalize_job(self.partial, tiles, self.colpart, self.ops.colmax_chunks(self.n), self.colkey, self.n, self.d,

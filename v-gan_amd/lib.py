@@ -160,14 +160,18 @@ def build_tiles(n, grad_mode, rank=0, world=1, tile=64):
     return list(buf), cnt
 
 
-def split_tiles(table, tile=64):
-    """Splits a tile table (torch int32 [count, 8], host) into (tiles of the XY / YY blocks, tiles of the XX block), each
-    re-ordered for the XCDs.  The XX tiles only feed the reported loss (sums, no gradient weights): the data-parallel step
-    runs them in a launch of their own, behind the gradient all-reduce."""
+def split_tiles(table, tile=64, yy_last=False):
+    """Splits a tile table (torch int32 [count, 8], host) into two parts, each re-ordered for the XCDs:
+    default   (tiles of the XY / YY blocks, tiles of the XX block) -- the XX tiles only feed the reported loss (sums, no
+              gradient weights), so a step may run them in another launch;
+    yy_last   (tiles of the XY / XX blocks, tiles of the YY block) -- the sharded front of a data-parallel step: the first
+              part reads no other rank's Y rows and runs beside their all-gather."""
     import torch
     lib = load()
+    slot = table[:, 4] & 3
+    first = (slot != 2) if yy_last else (slot != 0)
     parts = []
-    for keep in (table[:, 4] & 3 != 0, table[:, 4] & 3 == 0):
+    for keep in (first, ~first):
         sub = table[keep].contiguous()
         if sub.shape[0] > 1:
             buf = (ctypes.c_int32 * sub.numel())(*sub.reshape(-1).tolist())

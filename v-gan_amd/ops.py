@@ -47,14 +47,15 @@ class HipOps:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ---- host helpers -----------------------------------------------------------------------
-    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64, split_xx=False):
-        """split_xx: the table is returned as [XY and YY tiles ... | XX tiles ...] (each part in XCD order) together with the
-        length of the first part, for callers that launch the sum-only XX tiles separately."""
+    def build_tiles(self, n, grad_mode, rank=0, world=1, device=None, tile=64, split_xx=False, split=None):
+        """split_xx (= split "xx_last"): the table is returned as [XY and YY tiles ... | XX tiles ...] (each part in XCD order)
+        together with the length of the first part, for callers that launch the sum-only XX tiles separately; split "yy_last":
+        [XY and XX tiles ... | YY tiles ...] (the sharded data-parallel front: the first part needs no other rank's rows)."""
         flat, cnt = _lib.build_tiles(n, grad_mode, rank, world, tile)
         table = torch.tensor(flat, dtype=torch.int32).view(cnt, 8)
-        if split_xx:
-            main, xx = _lib.split_tiles(table, tile)
-            return torch.cat([main, xx]).to(device or "cuda"), main.shape[0]
+        if split_xx or split:
+            first, second = _lib.split_tiles(table, tile, yy_last=(split == "yy_last"))
+            return torch.cat([first, second]).to(device or "cuda"), first.shape[0]
         return table.to(device or "cuda")
 
     def colmax_chunks(self, n):

@@ -87,7 +87,7 @@ class NoKLStepEngine:
     def __init__(self, ops, generator, data, batch_size, batches_per_epoch, lr=0.007, weight_decay=0.04, penalty_weight=10.0,
                  seed=777, noise="device", rank=0, world=1, group=None, use_graph=True, loss_accum_scale=None,
                  generator_mode=None, force_exchange=False, mmd_precision=None, center_operand=True, overlap_exchange=None,
-                 fuse_update=None):
+                 fuse_update=None, front=None, chain_assoc=None):
         self.ops = ops
         self.dev = data.device
         self.rank, self.world, self.group = rank, world, group
@@ -108,7 +108,7 @@ class NoKLStepEngine:
         self.use_graph = bool(use_graph) and data.is_cuda
         self.graph = None
         self.graph_multi = None          # `steps_per_graph` steps in one graph (run_steps)
-        self._multi_failed = False
+        self.graph_blocks = {}           # block size -> captured graph (False: capture failed; the one-step graph keeps working)
         self.steps_per_graph = max(1, min(16, int(batches_per_epoch)))
         self.steps_done = 0
         self._xx_primed = False  # overlap mode: have the X-X sums of the upcoming batch been computed?
@@ -121,6 +121,25 @@ class NoKLStepEngine:
         # parallelism than the 1 600 workgroups of the streaming kernel (12.5 us vs 5.1 + 5.3 us), which costs more than the
         # removed launch boundary returns.  Kept off by default.
         self.fuse_update = (os.environ.get("VGAN_FUSE_UPDATE", "0") == "1") if fuse_update is None else bool(fuse_update)
+        # Data-parallel FRONT of the step (generator forward, mask, projection, operand split -- O(n d) work):
+        #   "replicated"  every rank produces all n rows of U and Y itself (module docstring): no exchange before the Gram; right
+        #                 while the front is a handful of microseconds (c3: ~10 us);
+        #   "sharded"     SURVEY 8e steps 1-2: a rank runs the logits product, mask / projection and operand split for ITS n/G rows
+        #                 only and the ranks all-gather the Y rows of the operand (split images or fp32 rows, their norms, and the
+        #                 column arg-max keys of the rows, which the step tail folds by max exactly like its own chunks).  The X half
+        #                 of the operand needs no parameter, so every rank gathers it from the resident data set itself, and the
+        #                 tiles that read no other rank's Y rows (XY and X-X: ~60 % of a rank's table) run BESIDE the all-gather.
+        #   "auto"        sharded when there is an exchange at all and n d >= 2^22 (c4 / c5; at those sizes the replicated front
+        #                 is 25-40 % of a 1/8 shard's step).
+        # Replicas stay bit-identical (every rank sees the same gathered bytes and the same all-reduced M_4); results agree with
+        # the replicated front to fp32 rounding of the logits product (its tile shape follows the row count).
+        want_front = front or os.environ.get("VGAN_DP_FRONT", "auto")
+        if want_front not in ("auto", "replicated", "sharded"):
+            raise ValueError(f"front must be 'auto', 'replicated' or 'sharded', got {want_front!r}")
+        if want_front == "sharded" and not (self.exchange and self.mode == "collapsed"):
+            raise ValueError("front='sharded' needs a data-parallel engine (world > 1 or force_exchange) with the collapsed generator")
+        self.front_sharded = (self.exchange and self.mode == "collapsed" and
+                              (want_front == "sharded" or (want_front == "auto" and n * data.shape[1] >= (1 << 22))))
 
         lin = [m for m in generator.main if isinstance(m, torch.nn.Linear)]
         assert len(lin) == 4
@@ -140,6 +159,7 @@ class NoKLStepEngine:
         self.za[:, L] = 1.0
         self.z_own = self.za[self.lo:self.lo + nl]
         self.logits = torch.zeros(n, d, **f32)           # all rows on every rank (replicated front, see the module docstring)
+        self.chain_flops = False
         if self.mode == "layered":
             self.gslab = torch.zeros(self.splits, self.fp.total, **f32) if self.splits > 1 else None
             gbase = self.gslab[0] if self.splits > 1 else self.fp.grad
@@ -166,6 +186,17 @@ class NoKLStepEngine:
             self.B3 = torch.zeros(e[4], e[2], **f32)
             self.B2 = torch.zeros(e[4], e[1], **f32)
             self.At1s = torch.zeros(e[1], e[0], **f32)  # snapshot of Wt_1 for the launch that also updates it (fuse_update)
+            # Association of the chain.  "depth" (above: suffix products, 3 + 2 dependent launches) buys latency with flops -- the
+            # product B_3 = Wt_4 Wt_3 alone is 2 e4 e3 e2 flop, 17 GFLOP of the 37 the chain costs at c5 (555 us of an 8.2 ms
+            # step, replicated on every rank of a data-parallel run).  "flops" keeps every product an [e_k, e_{k-1}] x
+            # [e_{k-1}, e0] one (At_k = Wt_k At_{k-1}, M_{k-1} = Wt_k^T M_k): 3 + 4 dependent launches, 17 GFLOP at c5.
+            # "auto": flops once the suffix product passes 1 GFLOP (c4: 2.2, c3: 0.12).
+            want_assoc = chain_assoc or os.environ.get("VGAN_CHAIN_ASSOC", "auto")
+            if want_assoc not in ("auto", "depth", "flops"):
+                raise ValueError(f"chain_assoc must be 'auto', 'depth' or 'flops', got {want_assoc!r}")
+            self.chain_flops = want_assoc == "flops" or (want_assoc == "auto" and 2.0 * e[4] * e[3] * e[2] >= 1e9)
+            if self.chain_flops:
+                self.fuse_update = False  # (the fused optimiser epilogue is written for the depth-first launches)
             pmap = torch.full((self.fp.total,), -1, dtype=torch.int32)
             for k in range(1, 5):
                 wk, wk1 = self.widths[k], self.widths[k - 1]
@@ -228,13 +259,13 @@ class NoKLStepEngine:
             # The backward product W . Z reads the SAME row-major images as the Gram (vgan_mmd_backward_bf3_rm: B fragments by
             # transposed LDS reads), so the operand preparation writes no transposed copy of Z (6.6 MB of scattered 16-byte stores
             # per step at c3).  VGAN_BWD_OPERAND=transposed keeps the round-1 form (ZTh / ZTl) for measurement.
-            self.rm_backward = os.environ.get("VGAN_BWD_OPERAND", "rowmajor") != "transposed"
+            self.rm_backward = self.front_sharded or os.environ.get("VGAN_BWD_OPERAND", "rowmajor") != "transposed"
             if self.rm_backward:
                 self.ZTh = self.ZTl = None
             else:
                 self.ZTh, self.ZTl = torch.zeros(self.kp, self.kn, **i16), torch.zeros(self.kp, self.kn, **i16)
             self.Wh, self.Wl = torch.zeros(nl, self.kn, **i16), torch.zeros(nl, self.kn, **i16)
-        self.fused_prepare = (self.bf3 and ops.bf3_fusable(n, d, self.logits.stride(0), data.stride(0), dp) and
+        self.fused_prepare = (self.bf3 and not self.front_sharded and ops.bf3_fusable(n, d, self.logits.stride(0), data.stride(0), dp) and
                               os.environ.get("VGAN_FUSED_PREPARE", "1") == "1")
         # collapsed generator, opt-in (VGAN_CHAIN_IN_MASK=1): the logits product inside the mask / projection launch (one wave per
         # batch row, the row's logits live in its registers anyway): one launch and 2 n d x 4 bytes of traffic less per step.
@@ -242,7 +273,7 @@ class NoKLStepEngine:
         # 6 316).  Every workgroup has to stage all of At_4 (163 KB, transposed through LDS in four chunks, each a dependent
         # global load + barrier) for its 8 rows: the carrying launch grows from 9.5 to 21.8 us, more than the 5.2 us launch it
         # replaces.  Off by default.
-        self.chain_in_mask = (self.mode == "collapsed" and ops.chain_fusable(n, d, data.stride(0), dp) and
+        self.chain_in_mask = (self.mode == "collapsed" and not self.front_sharded and ops.chain_fusable(n, d, data.stride(0), dp) and
                               (not self.bf3 or self.fused_prepare) and os.environ.get("VGAN_CHAIN_IN_MASK", "0") == "1")
         self._chain = None
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
@@ -271,6 +302,8 @@ class NoKLStepEngine:
         # side by side inside the graph slow each other (M_4 product 8.5 -> 13.0 us, mask backward 5.1 -> 6.9) and the fork /
         # join is not free.  The default is therefore the plain schedule; the option stays for stacks where streams are cheap.
         self.overlap = False if overlap_exchange is None else bool(overlap_exchange)
+        if self.front_sharded and self.overlap:
+            raise ValueError("overlap_exchange and front='sharded' are two schedules of the same exchange: choose one")
         self._side = torch.cuda.Stream(device=self.dev) if (self.overlap and data.is_cuda and overlap_exchange != "serial") else None
         # with the X half of the operand produced ahead of the step, the mask / projection launch writes the Y half only
         self.x_ahead = self.overlap and (not self.bf3 or self.rm_backward)
@@ -300,9 +333,14 @@ class NoKLStepEngine:
         # "some X-X tiles are computed LATER in the step than the launch that carries the step tail" (the tail is then split);
         # their carrier is the MMD backward launch when it has room (`xx_late_in_backward`), else the M_4 launch.
         self.xx_in_m4 = (self.bf3 and self.mode == "collapsed" and self.gram_tile == 64 and not self.overlap and not self.xx_ride and
+                         not self.front_sharded and
                          ops.linear_backward_params_xx_supported(nl, self.e[0], dp) and os.environ.get("VGAN_XX_IN_M4", "1") == "1")
         self._xx_m4 = self._fold = None
-        if self.overlap or self.xx_ride or self.xx_in_m4:
+        if self.front_sharded:
+            # [XY and X-X tiles | YY tiles]: the first part reads this rank's own Y rows and X columns only and runs while the
+            # other ranks' Y rows are still on their way (`_loss_backward_update_sharded`)
+            self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split="yy_last")
+        elif self.overlap or self.xx_ride or self.xx_in_m4:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
             if self.xx_in_m4:
                 # ... but only the X-X tiles the Gram launch has no free slot for: at two 74 KB workgroups per CU the chip holds
@@ -327,7 +365,7 @@ class NoKLStepEngine:
             self.xx_late_in_backward = (ops.mmd_backward_bf3_tile(nl, d, self.bsplits, self.bwd_tile) == 64 and late <= 512 - bwd_wgs)
         # the first-call bandwidth needs sum(L) over ALL pairs: computed by every rank from the full table (no collective)
         # (the calibration launch is the fp32 kernel: 64-wide tiles)
-        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not (self.overlap or self.xx_ride or self.xx_in_m4)) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
+        self.tiles_cal = self.tiles if (world == 1 and self.gram_tile == 64 and not (self.overlap or self.xx_ride or self.xx_in_m4 or self.front_sharded)) else ops.build_tiles(n, 0, 0, 1, device=self.dev)
         self.partial = torch.zeros(max(self.tiles.shape[0], self.tiles_cal.shape[0]), 4, **f32)
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.dev)
         self.bw = torch.zeros(1, **f32)
@@ -336,7 +374,12 @@ class NoKLStepEngine:
         self.loss_accum = torch.zeros(1, **f32)
         self.accum_scale = (1.0 / self.nb) if loss_accum_scale is None else float(loss_accum_scale)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.colpart = torch.zeros(ops.colmax_chunks(n) * d, dtype=torch.int64, device=self.dev)
+        # column arg-max keys of topk(U, 1, 0): per 64-row chunk, folded by max in the step tail.  Sharded front: one slice of
+        # chunks per rank (its rows' keys carry GLOBAL row numbers), all-gathered with the Y rows; the tail folds them all.
+        self.col_chunks = (world * ops.colmax_chunks(nl)) if self.front_sharded else ops.colmax_chunks(n)
+        self.colpart = torch.zeros(self.col_chunks * d, dtype=torch.int64, device=self.dev)
+        own = ops.colmax_chunks(nl) * d
+        self.colpart_own = self.colpart[rank * own:(rank + 1) * own] if self.front_sharded else self.colpart
         self.colkey = torch.zeros(d, dtype=torch.int64, device=self.dev)
 
     # ---- host-side controls ---------------------------------------------------------------------
@@ -432,17 +475,24 @@ class NoKLStepEngine:
         return self.fp.view(self.fp.grad, k)
 
     # ---- generator -----------------------------------------------------------------------------------
-    def _generator_forward(self):
+    def _generator_forward(self, own_rows=False):
+        """own_rows: logits of this rank's batch rows only (sharded front)."""
         ops = self.ops
         if self.mode == "layered":
             for k in range(4):
                 ops.linear_forward(self.acts[k], self.W[k], self.b[k], self.acts[k + 1])
             return
-        # prefix products At_k = Wt_k .. Wt_1 (Wt is kept current by the optimiser), two dependency levels:
+        # prefix products At_k = Wt_k .. Wt_1 (Wt is kept current by the optimiser)
         Wt, At = self.Wt, self.At
-        ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3)])
-        ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
-        if not self.chain_in_mask:  # otherwise logits = [z|1] . At_4^T are formed inside the mask / projection launch
+        if self.chain_flops:  # flop-minimal association: every product is [e_k, e_{k-1}] x [e_{k-1}, e0]
+            for k in (2, 3, 4):
+                ops.gemm_grouped([("NN", Wt[k], At[k - 1], At[k])])
+        else:                 # two dependency levels through the suffix products B_3, B_2
+            ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3)])
+            ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
+        if own_rows:
+            ops.linear_forward(self.z_own, At[4][:self.d], None, self.logits[self.lo:self.lo + self.nl])
+        elif not self.chain_in_mask:  # otherwise logits = [z|1] . At_4^T are formed inside the mask / projection launch
             ops.linear_forward(self.za, At[4][:self.d], None, self.logits)
 
     def _generator_backward_update(self, dist):
@@ -484,6 +534,15 @@ class NoKLStepEngine:
         # the long-K group on its 16-wave tiles)
         fused_noise = dict(next_noise=self.za, noise_cols=self.L, noise_ones_col=self.L, seed=self.seed,
                            step_counter=self.step_counter) if self.noise_mode == "device" else {}
+        if self.chain_flops:
+            # M_{k-1} = Wt_k^T M_k one after the other, each Gt_k = M_k At_{k-1}^T sharing a launch with the next M
+            Wt = self.Wt
+            ops.gemm_grouped([("TN", Wt[4], M[4], M[3])], fold=self._fold if self.xx_in_m4 else None)
+            ops.gemm_grouped([("TN", Wt[3], M[3], M[2]), ("NT", M[4], At[3], Gt[4])])
+            ops.gemm_grouped([("TN", Wt[2], M[2], M[1]), ("NT", M[3], At[2], Gt[3])])
+            ops.gemm_grouped([("NT", M[2], At[1], Gt[2])])
+            ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
+            return
         if not self.fuse_update:
             ops.gemm_grouped([("TN", self.Wt[4], M[4], M[3]), ("TN", self.B3, M[4], M[2]), ("TN", self.B2, M[4], M[1])],
                              fold=self._fold if self.xx_in_m4 else None)
@@ -592,6 +651,101 @@ class NoKLStepEngine:
         self._generator_backward_update(dist)
         self._join_prefetch()
 
+    # ---- sharded front ------------------------------------------------------------------
+    def _forward_sharded(self):
+        """Front of the step for this rank's n/G rows: logits, mask / projection, operand split, column keys."""
+        ops, n, nl, lo, d = self.ops, self.n, self.nl, self.lo, self.d
+        if self.noise_mode == "device" and self.steps_done == 0:
+            ops.noise_normal(self.za, self.seed, self.step_counter, 0, cols=self.L, ones_col=self.L)
+        self._generator_forward(own_rows=True)
+        rowsel = dict(row_cursor=self.step_counter, row_batches=self.nb, row_stride=n)
+        own, yown = slice(lo, lo + nl), slice(n + lo, n + lo + nl)
+        # X half of the operand, ALL batch rows (every rank's XY tiles read all X columns; no parameter enters, so it is
+        # gathered from the resident data set instead of exchanged): centred rows + norms (+ split images)
+        if self.bf3:
+            ops.gather_rows_split(self.data, self.perm, self.center, None, self.sqn[:n], True, self.Zh[:n], self.Zl[:n], **rowsel)
+        else:
+            ops.gather_rows_split(self.data, self.perm, self.center, self.Z[:n], self.sqn[:n], False, **rowsel)
+        # (bf16x3: the backward's multiplier is the fp32 X row of an own row -- written here; fp32 mode has it from the gather)
+        ops.mask_project_forward(self.logits[own], self.data, self.perm, self.S_own, None, self.Z[own] if self.bf3 else None, self.Z[yown],
+                                 None, self.sqn[yown], row_offset=lo, center=self.center, norm_split=self.bf3, **rowsel)
+        if self.bf3:
+            ops.mmd_bf3_prepare(self.Z[yown], nl, d, self.Zh[yown], self.Zl[yown])
+        ops.colmax_partial(self.S_own, lo, self.colpart_own)
+
+    def _all_gather(self, dist, out, own):
+        """all-gather of `own` (this rank's slice OF `out`, in place).  A process group smaller than the engine's world is the
+        one-GPU shard emulation of tools/dp_selftest.py: the collective is issued on the slice alone."""
+        size = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if size != self.world:
+            out = own
+        if own.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal of several ranks on ONE GPU (tests/test_dp_gpu.py, bench.py with VGAN_BENCH_BACKEND=gloo): through the host
+            host = out.cpu()
+            dist.all_gather_into_tensor(host, own.cpu(), group=self.group)
+            out.copy_(host)
+            return None
+        return dist.all_gather_into_tensor(out, own, group=self.group, async_op=True)
+
+    def _exchange_front(self, dist):
+        """The ONE exchange of the sharded front: Y rows of the operand (+ norms) and the column keys, all-gathered in place.
+        Returns the pending work handles; the caller runs the tiles that need none of it meanwhile."""
+        n, nl, lo = self.n, self.nl, self.lo
+        yown = slice(n + lo, n + lo + nl)
+        works = []
+        if self.bf3:  # (int16 images travel as int32 words: gloo has no 16-bit integer type)
+            for img in (self.Zh, self.Zl):
+                works.append(self._all_gather(dist, img[n:2 * n].view(torch.int32), img[yown].view(torch.int32)))
+        else:
+            works.append(self._all_gather(dist, self.Z[n:], self.Z[yown]))
+        works.append(self._all_gather(dist, self.sqn[n:], self.sqn[yown]))
+        works.append(self._all_gather(dist, self.colpart, self.colpart_own))
+        return works
+
+    def _loss_backward_update_sharded(self, all_rows_here=False):
+        """Gram (own Y rows x all columns + a share of the X-X triangle), backward, mask backward, M_4, all-reduce, chain
+        backward, optimiser -- after `_forward_sharded` (or, all_rows_here: after the replicated front of the calibration
+        step, which has produced every row on every rank: nothing to exchange)."""
+        ops, n, nl, lo, d = self.ops, self.n, self.nl, self.lo, self.d
+        dist = self._collect()
+        works = []
+        if all_rows_here:
+            if self.bf3:
+                ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl)
+            self.colpart.zero_()
+            ops.colmax_partial(self.S, 0, self.colpart[:ops.colmax_chunks(n) * d])
+        else:
+            works = self._exchange_front(dist)
+        na = self.n_main
+
+        def gram(t0, t1):
+            if t1 <= t0:
+                return
+            if self.bf3:
+                ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles[t0:t1], self.Wh, self.Wl, n + lo, self.partial[t0:t1],
+                                 tile=self.gram_tile)
+            else:
+                ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles[t0:t1], False, self.Wg, n + lo, self.partial[t0:t1])
+
+        gram(0, na)                      # XY and X-X tiles: beside the all-gather
+        for w in works:
+            if w is not None:
+                w.wait()
+        gram(na, self.tiles.shape[0])    # YY tiles: every rank's Y rows
+        if self._fin is None:
+            self._fin = ops.finalize_job(self.partial, self.tiles, self.colpart, self.col_chunks, self.colkey, n, d,
+                                         self.pen if self.rank == 0 else 0.0, self.stats, self.loss, self.loss_accum, self.accum_scale,
+                                         self.step_counter)
+        gstride = nl * self.dp
+        if self.bf3:
+            ops.mmd_backward_bf3_rm(self.Wh, self.Wl, self.Zh, self.Zl, 2 * n, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU,
+                                    self.bsplits, gstride, self._fin, mul_shift=self.center, tile=self.bwd_tile)
+        else:
+            ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride, self._fin,
+                             mul_shift=self.center)
+        ops.mask_backward(self.gU, self.S_own, self.colkey, self.pen, lo, self.dlogits, self.bsplits, gstride)
+        self._generator_backward_update(dist)
+
     def _late_xx_job(self):
         """The X-X tiles the Gram launch had no slot for, as a job for the launch that carries them."""
         if self._xx_m4 is None:
@@ -601,20 +755,27 @@ class NoKLStepEngine:
         return self._xx_m4
 
     def _step_body(self):
-        self._forward()
-        self._loss_backward_update()
+        if self.front_sharded:
+            self._forward_sharded()
+            self._loss_backward_update_sharded()
+        else:
+            self._forward()
+            self._loss_backward_update()
 
     def step(self):
         """Runs one training step asynchronously.  The first step also calibrates the bandwidth."""
         if not self.has_bw:
             if self.overlap:  # no step ran before this one: the X half of its operand is produced here ...
                 self._prefetch_x_operand()
-            self._forward()
+            self._forward()  # (all rows on every rank, whatever the front mode: the calibration below needs them all)
             self._calibrate()
             if self.overlap or self.xx_ride:  # ... and its X-X sums here, with the fresh bandwidth
                 self._xx_tiles()
                 self._xx_primed = True
-            self._loss_backward_update()
+            if self.front_sharded:
+                self._loss_backward_update_sharded(all_rows_here=True)
+            else:
+                self._loss_backward_update()
         elif self.use_graph and self.steps_done > 0:
             if self.graph is None:
                 self._capture()
@@ -642,17 +803,28 @@ class NoKLStepEngine:
             raise ValueError("run_steps needs the device noise stream: host-provided noise is set per step (set_noise + step)")
         m = self.steps_per_graph
         while count > 0:
-            if (count >= m and m > 1 and self.use_graph and self.has_bw and self.steps_done > 0 and self.noise_mode == "device" and
+            blk = min(count, m)
+            if (blk > 1 and self.use_graph and self.has_bw and self.steps_done > 0 and self.noise_mode == "device" and
                     self.graph is not None):
-                if self.graph_multi is None and not self._multi_failed:
-                    self._capture_multi(m)
-                if self.graph_multi is not None:
-                    self.graph_multi.replay()
-                    self.steps_done += m
-                    count -= m
+                g = self._block_graph(blk)
+                if g is not None:
+                    g.replay()
+                    self.steps_done += blk
+                    count -= blk
                     continue
             self.step()
             count -= 1
+
+    def _block_graph(self, steps):
+        """The graph holding `steps` consecutive steps (captured at first use), or None.  An epoch of nb steps replays
+        nb // 16 graphs of 16 and one of nb % 16; at most four block sizes are kept (a caller that asks for ever new
+        remainders gets the one-step graph for them)."""
+        g = self.graph_blocks.get(steps)
+        if g is None and len(self.graph_blocks) < 4:
+            g = self.graph_blocks[steps] = self._capture_graph(steps) or False
+        if steps == self.steps_per_graph:
+            self.graph_multi = g or None
+        return g or None
 
     def _capture_graph(self, steps):
         torch.cuda.synchronize()
@@ -674,10 +846,6 @@ class NoKLStepEngine:
         self.graph = self._capture_graph(1)
         if self.graph is None:
             self.use_graph = False
-
-    def _capture_multi(self, steps):
-        self.graph_multi = self._capture_graph(steps)
-        self._multi_failed = self.graph_multi is None  # the one-step graph keeps working
 
     # ---- sampling (generate_subspaces) ---------------------------------------------------------
     def generator_logits(self, z):

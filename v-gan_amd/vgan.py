@@ -106,8 +106,11 @@ class _RunFolder:
         history.to_csv(folder / "train_history" / f"generator_loss_{run_number}.csv", header=False, index=False)
         # params.csv: one row per run number; an existing file keeps its other rows, this run's row is added or replaced
         table_path = folder / "params.csv"
-        table = pd.read_csv(table_path, index_col=0) if table_path.is_file() else pd.DataFrame()
-        row = pd.DataFrame.from_dict({run_number: self.get_params()}, orient="index")
+        # (reference quirk kept, src/vgan.py:130-132: a params.csv that does not exist yet gets its first row under index 0
+        #  whatever run_number is)
+        fresh = not table_path.is_file()
+        table = pd.DataFrame() if fresh else pd.read_csv(table_path, index_col=0)
+        row = pd.DataFrame.from_dict({0 if fresh else run_number: self.get_params()}, orient="index")
         table = row.combine_first(table)[list(row.columns) + [c for c in table.columns if c not in row.columns]]
         table.sort_index().to_csv(table_path)
         self._write_loss_plot(folder)
@@ -411,6 +414,14 @@ class VGAN(_RunFolder):
         self.detector_optimizer = "Adadelta"
         loss_function = MMDLossConstrained(weight=self.temperature)
 
+        rank, world = _dist_info()
+        if world > 1:
+            # KLStepEngine has no row sharding: under torchrun every rank would train the whole problem and report it as if it
+            # were a share.  The data-parallel path is VGAN_no_kl's (trainer.py); say so instead of silently replicating.
+            import warnings
+            warnings.warn(f"vgan_amd: VGAN.fit is not data-parallel -- torch.distributed is initialised with {world} ranks and "
+                          f"rank {rank} will train the WHOLE problem on its own GPU (identical replicas, no speed-up); "
+                          "use VGAN_no_kl for the row-sharded step", RuntimeWarning, stacklevel=2)
         data = torch.as_tensor(X).to(device=device, dtype=torch.float32).contiguous()
         batch_number = train_size // self.batch_size
         engine = KLStepEngine(self._ops(), generator, detector, data, self.batch_size, self.lr_D, self.weight_decay,
