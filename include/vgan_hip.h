@@ -296,6 +296,9 @@ int vgan_mmd_backward_bf3_rm_xx(const uint16_t* Wh, const uint16_t* Wl, int ldw,
  * forward/backward is a chain of small matrix products (see vgan_homogeneous_pack); products of one
  * dependency level share a launch.  kind: NN C[m,n] = A[m,k] . B[k,n];  NT C = A[m,k] . B[n,k]^T;
  * TN C = A[k,m]^T . B[k,n].  All operands row-major with leading dimensions lda / ldb / ldc.
+ * splitk > 1: the contraction is cut into splitk slices run by different workgroups (for a long contraction over few
+ * output tiles); slice s writes its PARTIAL product to slab s of C, slabs m * ldc floats apart, and the caller sums the
+ * slabs in fixed order (vgan_reduce_slabs) -- deterministic, so data-parallel replicas stay bit-identical.  0 / 1: no split.
  * ------------------------------------------------------------------------------------------- */
 #define VGAN_GEMM_MAX_GROUP 4
 #define VGAN_GEMM_NN 0
@@ -305,7 +308,7 @@ typedef struct vgan_gemm_problem {
     const float* a;
     const float* b;
     float* c;
-    int32_t kind, m, n, k, lda, ldb, ldc, pad;
+    int32_t kind, m, n, k, lda, ldb, ldc, splitk;
 } vgan_gemm_problem;
 int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_t stream);
 /* The same launch with work riding in it (each part optional; a dependent launch costs ~5 us whatever its size, so the

@@ -423,7 +423,8 @@ class CpuOps:
 
     def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None, fold=None):
         outs = []
-        for kind, A, B, C in problems:  # all reads before any write: the products are independent by contract
+        problems = [tuple(q[:4]) if len(q) == 4 or q[4] <= 1 else (q[0], q[1], q[2], q[3], q[4]) for q in problems]
+        for kind, A, B, *_ in problems:  # all reads before any write: the products are independent by contract
             a, b = _np(A).astype(np.float64), _np(B).astype(np.float64)
             outs.append(a @ b if kind == "NN" else a @ b.T if kind == "NT" else a.T @ b)
         if noise is not None:  # reads the step counter as the launch finds it
@@ -431,13 +432,17 @@ class CpuOps:
                               ones_col=noise["noise_ones_col"])
         if copy is not None:
             copy[1].copy_(copy[0])
-        for (_, _, _, C), r in zip(problems, outs):
+        for q, r in zip(problems, outs):
+            C = q[3]
+            if len(q) > 4:  # split-K slabs: the CPU stand-in puts the whole product in slab 0
+                C.zero_()
+                C = C[0]
             C.copy_(torch.as_tensor(r))
         if fold is not None:
             self.mmd_finalize(*fold[0], **fold[1])
         if adadelta is not None:
             a = adadelta
-            grads = [C for _, _, _, C in problems] + ([a["extra_grad"]] if a.get("extra_grad") is not None else [])
+            grads = [q[3] for q in problems] + ([a["extra_grad"]] if a.get("extra_grad") is not None else [])
             for (w, off_w, off_b, out, inp), G in zip(a["layers"], grads):
                 for off, cnt, g in ((off_w, out * inp, G[:out, :inp].reshape(-1)), (off_b, out, G[:out, inp].reshape(-1))):
                     sl = slice(off, off + cnt)

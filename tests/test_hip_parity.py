@@ -1157,6 +1157,40 @@ def test_gemm_grouped_vs_numpy(ops, case):
     assert float(C[:, 40:].abs().max()) == 0.0
 
 
+def test_gemm_grouped_split_k_slabs(ops):
+    """vgan_gemm_problem.splitk: the contraction cut into slices run by different workgroups, partial products in slabs that
+    vgan_reduce_slabs sums (the chain products of c4 / c5: long contraction, few output tiles).  All three kinds in one launch
+    beside an unsplit product, ragged slice lengths (K no multiple of the slice), against float64 numpy; and two runs give
+    the same bits (no atomics)."""
+    rng = np.random.default_rng(77)
+    T = lambda *shape: torch.as_tensor(rng.normal(size=shape).astype(np.float32)).cuda()
+    probs = [("TN", T(1100, 260), T(1100, 132), 5), ("NN", T(516, 1028), T(1028, 132), 4), ("NT", T(200, 900), T(136, 900), 3),
+             ("NT", T(260, 132), T(516, 132), 1)]
+    outs = []
+    for rep in range(2):
+        launch, dst = [], []
+        for kind, A, B, sp in probs:
+            m, n = (A.shape[1] if kind == "TN" else A.shape[0]), (B.shape[0] if kind == "NT" else B.shape[1])
+            if sp > 1:
+                slabs = torch.full((sp, m, n), float("nan"), device="cuda")
+                launch.append((kind, A, B, slabs, sp))
+                dst.append((slabs, torch.empty(m, n, device="cuda"), sp))
+            else:
+                C = torch.full((m, n), float("nan"), device="cuda")
+                launch.append((kind, A, B, C))
+                dst.append((None, C, 1))
+        ops.gemm_grouped(launch)
+        for slabs, C, sp in dst:
+            if sp > 1:
+                ops.reduce_slabs(slabs, C.numel(), sp, C)
+        outs.append([host(C).copy() for _, C, _ in dst])
+    for (kind, A, B, sp), got, again in zip(probs, outs[0], outs[1]):
+        a, b = host(A).astype(np.float64), host(B).astype(np.float64)
+        want = a @ b if kind == "NN" else a @ b.T if kind == "NT" else a.T @ b
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * np.abs(want).max(), err_msg=f"{kind} x{sp}")
+        assert np.array_equal(got, again)
+
+
 @pytest.mark.parametrize("n,d,mode", [(1024, 784, 1), (384, 200, 2), (300, 130, 1)])
 def test_gram_bf3_tile128_equals_tile64(ops, n, d, mode):
     """The 128x128 split-bf16 Gram kernel against the 64x64 one on the same operands: same block sums (to fp32 summation

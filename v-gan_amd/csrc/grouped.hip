@@ -16,8 +16,21 @@ struct GroupedArgs {
     vgan_gemm_problem p[VGAN_GEMM_MAX_GROUP];
     int tile_start[VGAN_GEMM_MAX_GROUP + 1];
     int ks[VGAN_GEMM_MAX_GROUP];
+    int split[VGAN_GEMM_MAX_GROUP];   // K slices of the problem (vgan_gemm_problem.splitk): slice s writes slab s of C
+    int kchunk[VGAN_GEMM_MAX_GROUP];  // contraction indices per slice (a multiple of QBK)
     int count;
 };
+
+// One K slice of a split problem as a problem of its own: operands advanced along the contraction, output = slab `slice`.
+__device__ __forceinline__ vgan_gemm_problem k_slice(vgan_gemm_problem q, int slice, int kchunk) {
+    const int k0 = slice * kchunk;
+    q.c += (long)slice * q.m * q.ldc;
+    if (q.kind == VGAN_GEMM_NN) { q.a += k0; q.b += (long)k0 * q.ldb; }
+    else if (q.kind == VGAN_GEMM_NT) { q.a += k0; q.b += k0; }
+    else { q.a += (long)k0 * q.lda; q.b += (long)k0 * q.ldb; }
+    q.k = min(kchunk, q.k - k0);
+    return q;
+}
 
 // What may ride in a grouped launch besides its products (vgan_gemm_grouped_ex): a plain copy, the Adadelta update as
 // the products' epilogue (+ one element-wise layer whose gradient already sits in memory), and the next step's noise draw.
@@ -172,8 +185,13 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_grouped_kernel(GroupedArgs g, 
 #pragma unroll
     for (int i = 1; i < VGAN_GEMM_MAX_GROUP; ++i)
         if (i < g.count && (int)blockIdx.x >= g.tile_start[i]) qi = i;
-    const vgan_gemm_problem& q = g.p[qi];
-    const int t = blockIdx.x - g.tile_start[qi];
+    vgan_gemm_problem q = g.p[qi];
+    int t = blockIdx.x - g.tile_start[qi];
+    if (g.split[qi] > 1) {  // (block-uniform) tiles of slice 0, then of slice 1, ...
+        const int per = (g.tile_start[qi + 1] - g.tile_start[qi]) / g.split[qi];
+        q = k_slice(q, t / per, g.kchunk[qi]);
+        t %= per;
+    }
     // operand images: KC = contraction index contiguous ([mn][K]), MC = output index contiguous ([K][mn])
     if (q.kind == VGAN_GEMM_NN) {         // C = A[m,k] . B[k,n]
         if (g.ks[qi]) tile_ks<KC, MC, VEC, 4, EPI>(q, t, lds, x, qi); else tile64<KC, MC, VEC, EPI>(q, t, lds, x, qi);
@@ -220,7 +238,7 @@ extern "C" int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count
     GroupedArgs g{};
     GroupedExtras x{};
     g.count = count;
-    bool vec = true;
+    bool vec = true, any_split = false;
     int tiles = 0;
     for (int i = 0; i < count; ++i) {
         const vgan_gemm_problem& q = problems[i];
@@ -236,7 +254,18 @@ extern "C" int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count
         g.ks[i] = (q.k >= 128 && t32 <= 512) ? 1 : 0;
         g.p[i] = q;
         g.tile_start[i] = tiles;
-        tiles += g.ks[i] ? ((q.m + 31) / 32) * ((q.n + 31) / 32) : (int)t64;
+        // split-K across WORKGROUPS (splitk > 1): a product with a long contraction and too few 64 x 64 tiles to load the chip
+        // evenly (c5: M_3 = Wt_4^T M_4 is 165 tiles of K = 4100) is cut into splitk slices of the contraction; slice s writes
+        // its partial product to slab s of C (slabs m * ldc floats apart) and the caller sums them in fixed order
+        // (vgan_reduce_slabs) -- no atomics, so replicas of a data-parallel run stay bit-identical.
+        g.split[i] = q.splitk > 1 ? q.splitk : 1;
+        if (g.split[i] > 1) {
+            g.kchunk[i] = ((q.k + g.split[i] - 1) / g.split[i] + QBK - 1) / QBK * QBK;
+            VGAN_CHECK_ARG(g.split[i] <= 64 && (long)(g.split[i] - 1) * g.kchunk[i] < q.k);  // every slice holds work
+            g.ks[i] = 0;
+            any_split = true;
+        }
+        tiles += g.ks[i] ? ((q.m + 31) / 32) * ((q.n + 31) / 32) : (int)t64 * g.split[i];
     }
     for (int i = count; i <= VGAN_GEMM_MAX_GROUP; ++i) g.tile_start[i] = tiles;
     bool epi = false;
@@ -250,7 +279,7 @@ extern "C" int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count
             x.copy_blocks = extra_grid(e.copy_count);
         }
         if (e.adadelta) {
-            VGAN_CHECK_ARG(e.p && e.sq_avg && e.acc_delta);
+            VGAN_CHECK_ARG(e.p && e.sq_avg && e.acc_delta && !any_split);  // (the optimiser epilogue needs the whole product)
             epi = true;
             x.adadelta = 1;
             x.p = e.p; x.sq = e.sq_avg; x.acc = e.acc_delta;
@@ -290,7 +319,7 @@ extern "C" int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count
         kmin = problems[i].k < kmin ? problems[i].k : kmin;
         t32 += ((problems[i].m + 31) / 32) * ((problems[i].n + 31) / 32);
     }
-    if (vec && kmin >= 96 && t32 <= 256 && !epi && x.noise_blocks == 0) {  // (copy and fold jobs ride in this variant too)
+    if (vec && kmin >= 96 && t32 <= 256 && !epi && x.noise_blocks == 0 && !any_split) {  // (copy and fold jobs ride in this variant too)
         int acc = 0;
         for (int i = 0; i < count; ++i) {
             g.ks[i] = 1;

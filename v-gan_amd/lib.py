@@ -22,7 +22,7 @@ class FinalizeJob(ctypes.Structure):
 class GemmProblem(ctypes.Structure):
     """struct vgan_gemm_problem (include/vgan_hip.h)."""
     _fields_ = [("a", _p), ("b", _p), ("c", _p), ("kind", ctypes.c_int32), ("m", ctypes.c_int32), ("n", ctypes.c_int32),
-                ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("pad", ctypes.c_int32)]
+                ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("splitk", ctypes.c_int32)]
 
 
 class LogitsChain(ctypes.Structure):

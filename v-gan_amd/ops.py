@@ -373,8 +373,10 @@ class HipOps:
 
     def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None, fold=None):
         """problems: up to 4 tuples (kind, A, B, C) with kind in "NN" (C = A.B), "NT" (C = A.B^T), "TN" (C = A^T.B); 2-D float32
-        tensors with unit inner stride.  One launch; the products must not depend on each other.  Jobs that may ride in the
-        launch (vgan_gemm_grouped_ex):
+        tensors with unit inner stride.  One launch; the products must not depend on each other.  A fifth tuple element
+        `splits` > 1 cuts the contraction into that many slices run by different workgroups: C is then a contiguous
+        [splits, m, n] tensor of partial products for the caller to sum (reduce_slabs).  Jobs that may ride in the launch
+        (vgan_gemm_grouped_ex):
           copy = (src, dst)             contiguous float32 tensors of equal size, dst <- src;
           adadelta = dict(p, sq, acc, lr, rho, eps, weight_decay, grad_scale, layers=[(w_packed, off_w, off_b, out, in) per
                      problem (+ one more with extra_grad)], extra_grad=None): the optimiser update in the products' epilogue;
@@ -382,7 +384,11 @@ class HipOps:
           fold = a finalize_job() run by one surplus workgroup (the late half of a split step tail)."""
         assert 1 <= len(problems) <= _lib.GEMM_MAX_GROUP
         arr = (_lib.GemmProblem * len(problems))()
-        for q, (kind, A, B, C) in zip(arr, problems):
+        for q, (kind, A, B, C, *rest) in zip(arr, problems):
+            q.splitk = int(rest[0]) if rest else 1
+            if q.splitk > 1:
+                assert C.dim() == 3 and C.shape[0] == q.splitk and C.is_contiguous()
+                C = C[0]
             _mat(A, "A"), _mat(B, "B"), _mat(C, "C")
             if kind == "NN":
                 (m, k), (k2, n), code = A.shape, B.shape, _lib.GEMM_NN

@@ -197,6 +197,18 @@ class NoKLStepEngine:
             self.chain_flops = want_assoc == "flops" or (want_assoc == "auto" and 2.0 * e[4] * e[3] * e[2] >= 1e9)
             if self.chain_flops:
                 self.fuse_update = False  # (the fused optimiser epilogue is written for the depth-first launches)
+                # Products with a long contraction over few 64 x 64 output tiles (c5: M_3 = Wt_4^T M_4 is 165 tiles of K = 4100 on
+                # 256 CUs, 116 us for 4.4 GFLOP) are cut into K slices run by different workgroups -- ~1000 work items per
+                # product -- whose partial slabs a small launch sums in fixed order (no atomics: replicas stay bit-identical).
+                def split_of(m, n_, k):
+                    t64 = ((m + 63) // 64) * ((n_ + 63) // 64)
+                    return 1 if 2.0 * m * n_ * k < 2.5e8 else max(1, min(8, 1024 // t64, k // 256))
+                self.fwd_split = {k: split_of(e[k], e[0], e[k - 1]) for k in (2, 3, 4)}       # At_k = Wt_k At_{k-1}
+                self.bwd_split = {k: split_of(e[k - 1], e[0], e[k]) for k in (4, 3, 2)}       # M_{k-1} = Wt_k^T M_k
+                if os.environ.get("VGAN_CHAIN_SPLITK", "1") != "1":  # measurement knob
+                    self.fwd_split, self.bwd_split = {k: 1 for k in (2, 3, 4)}, {k: 1 for k in (4, 3, 2)}
+                need = max([self.fwd_split[k] * e[k] * e[0] for k in (2, 3, 4)] + [self.bwd_split[k] * e[k - 1] * e[0] for k in (4, 3, 2)])
+                self.chain_ws = torch.zeros(need, **f32)
             pmap = torch.full((self.fp.total,), -1, dtype=torch.int32)
             for k in range(1, 5):
                 wk, wk1 = self.widths[k], self.widths[k - 1]
@@ -340,6 +352,14 @@ class NoKLStepEngine:
             # [XY and X-X tiles | YY tiles]: the first part reads this rank's own Y rows and X columns only and runs while the
             # other ranks' Y rows are still on their way (`_loss_backward_update_sharded`)
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split="yy_last")
+            # Both launches run in rounds of `slots` resident workgroups (128-wide tiles: one 512-thread workgroup per CU; 64-wide:
+            # two), so a first part of 3 x 256 + 4 tiles pays a fourth round for the four (c5, 8 ranks: 772 + 484 tiles, 352 + 198
+            # us against ~100 us per round).  The boundary may move DOWN freely -- the second launch runs after the all-gather and
+            # can take any tile -- so the tail of the first part goes over when the second part has free slots for it.
+            slots = 256 if self.gram_tile == 128 else (512 if self.bf3 else 1024)  # (fp32 kernel: 36 KB of LDS, four workgroups per CU)
+            tail, second = self.n_main % slots, self.tiles.shape[0] - self.n_main
+            if 0 < tail < self.n_main and -(-(second + tail) // slots) == -(-second // slots):
+                self.n_main -= tail
         elif self.overlap or self.xx_ride or self.xx_in_m4:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
             if self.xx_in_m4:
@@ -486,7 +506,12 @@ class NoKLStepEngine:
         Wt, At = self.Wt, self.At
         if self.chain_flops:  # flop-minimal association: every product is [e_k, e_{k-1}] x [e_{k-1}, e0]
             for k in (2, 3, 4):
-                ops.gemm_grouped([("NN", Wt[k], At[k - 1], At[k])])
+                sp = self.fwd_split[k]
+                if sp > 1:
+                    ops.gemm_grouped([("NN", Wt[k], At[k - 1], self._slabs(sp, At[k]), sp)])
+                    ops.reduce_slabs(self.chain_ws, At[k].numel(), sp, At[k])
+                else:
+                    ops.gemm_grouped([("NN", Wt[k], At[k - 1], At[k])])
         else:                 # two dependency levels through the suffix products B_3, B_2
             ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3)])
             ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
@@ -494,6 +519,10 @@ class NoKLStepEngine:
             ops.linear_forward(self.z_own, At[4][:self.d], None, self.logits[self.lo:self.lo + self.nl])
         elif not self.chain_in_mask:  # otherwise logits = [z|1] . At_4^T are formed inside the mask / projection launch
             ops.linear_forward(self.za, At[4][:self.d], None, self.logits)
+
+    def _slabs(self, splits, like):
+        """[splits, rows, cols] view of the chain workspace for the K-slice partial products of a matrix shaped like `like`."""
+        return self.chain_ws[:splits * like.numel()].view(splits, like.shape[0], like.shape[1])
 
     def _generator_backward_update(self, dist):
         """dlogits -> parameter gradients -> (all-reduce) -> Adadelta."""
@@ -537,9 +566,14 @@ class NoKLStepEngine:
         if self.chain_flops:
             # M_{k-1} = Wt_k^T M_k one after the other, each Gt_k = M_k At_{k-1}^T sharing a launch with the next M
             Wt = self.Wt
-            ops.gemm_grouped([("TN", Wt[4], M[4], M[3])], fold=self._fold if self.xx_in_m4 else None)
-            ops.gemm_grouped([("TN", Wt[3], M[3], M[2]), ("NT", M[4], At[3], Gt[4])])
-            ops.gemm_grouped([("TN", Wt[2], M[2], M[1]), ("NT", M[3], At[2], Gt[3])])
+            for k in (4, 3, 2):
+                sp = self.bwd_split[k]
+                probs = [("TN", Wt[k], M[k], self._slabs(sp, M[k - 1]), sp) if sp > 1 else ("TN", Wt[k], M[k], M[k - 1])]
+                if k < 4:
+                    probs.append(("NT", M[k + 1], At[k], Gt[k + 1]))
+                ops.gemm_grouped(probs, fold=self._fold if (self.xx_in_m4 and k == 4) else None)
+                if sp > 1:
+                    ops.reduce_slabs(self.chain_ws, M[k - 1].numel(), sp, M[k - 1])
             ops.gemm_grouped([("NT", M[2], At[1], Gt[2])])
             ops.adadelta_step_packed(self.fp.flat, self.pmap, self.Gt_all, self.Wt_all, self.fp.sq, self.fp.acc, **adadelta, **fused_noise)
             return
