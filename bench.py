@@ -142,13 +142,16 @@ def kernel_rooflines(eng):
     nl, lo = eng.nl, eng.lo
     iters = 30 if n <= 2048 else 6
     tl = eng.tiles.cpu()
-    edge = eng.gram_tile
+    er, ec = (256, 128) if eng.gram_tile == 256 else (eng.gram_tile, eng.gram_tile)  # tile 256 = 256 rows x 128 columns
 
     def pairs_of(t):  # pairs a tile table covers, mirrored halves of a symmetric tile counted once
-        r = (torch.minimum(t[:, 0] + edge, t[:, 2]) - t[:, 0]).double()
-        c = (torch.minimum(t[:, 1] + edge, t[:, 3]) - t[:, 1]).double()
-        diag = (t[:, 0] % n == t[:, 1] % n) & ((t[:, 0] >= n) == (t[:, 1] >= n))
-        return float((torch.where(diag, r * (c + 1) / 2, r * c)).sum())
+        r = (torch.minimum(t[:, 0] + er, t[:, 2]) - t[:, 0]).double()
+        c = (torch.minimum(t[:, 1] + ec, t[:, 3]) - t[:, 1]).double()
+        # the tiles of a symmetric block's diagonal squares (one 64 / 128 tile, two 256 x 128 tiles side by side) hold each
+        # unordered pair twice: r (r + 1) / 2 unique pairs per square of edge r
+        same = ((t[:, 0] >= n) == (t[:, 1] >= n)) & (t[:, 1] % n >= t[:, 0] % n) & (t[:, 1] % n < t[:, 0] % n + er) & ((t[:, 4] & 4) == 0) \
+            & ((t[:, 4] & 3) != 1)
+        return float((torch.where(same, r * (c + 1) / 2 if er == ec else r * c / 2 + c / 2, r * c)).sum())
 
     out = {}
     bwd_flop = 4.0 * nl * n * D_FEAT
@@ -167,7 +170,7 @@ def kernel_rooflines(eng):
     out["mmd_backward_kernel<4,2>"] = {"ms": ms, "tflops": bwd_flop / (ms * 1e-3) / 1e12, "flop": bwd_flop}
     if eng.bf3:
         gs = nl * eng.dp
-        gname = "mmd_gram_bf3_big_kernel" if eng.gram_tile == 128 else "mmd_gram_bf3_kernel<64>"
+        gname = {256: "mmd_gram_bf3_wide_kernel", 128: "mmd_gram_bf3_big_kernel"}.get(eng.gram_tile, "mmd_gram_bf3_kernel<64>")
         # as the step launches it: one launch of the first n_main tiles (every XY / YY tile and as many X-X tiles as the launch has
         # free slots for; the late X-X tiles ride in another launch) -- or, sharded front, the whole table in two launches
         nt = eng.tiles.shape[0] if eng.front_sharded else eng.n_main
@@ -181,8 +184,8 @@ def kernel_rooflines(eng):
                                                       eng.partial[nt:], tile=eng.gram_tile), iters)
             out[gname + " [X-X tiles alone]"] = {"ms": ms, "tflops": xx_flop / (ms * 1e-3) / 1e12, "flop": xx_flop,
                                                         "tiles": int(eng.tiles.shape[0] - nt)}
-        big_bwd = ops.mmd_backward_bf3_tile(nl, d, eng.bsplits, eng.bwd_tile) == 128  # the library's own choice
-        bname = "mmd_backward_bf3_big_kernel" if big_bwd else "mmd_backward_bf3_kernel<64>"
+        bwd_edge = ops.mmd_backward_bf3_tile(nl, d, eng.bsplits, eng.bwd_tile) if eng.rm_backward else min(128, ops.mmd_backward_bf3_tile(nl, d, eng.bsplits, eng.bwd_tile))
+        bname = {256: "mmd_backward_bf3_wide_kernel", 128: "mmd_backward_bf3_big_kernel"}.get(bwd_edge, "mmd_backward_bf3_kernel<64>")  # the library's own choice
         if eng.rm_backward:  # B operand = the Gram's row-major images (transposed LDS reads)
             ms = time_kernel(lambda: ops.mmd_backward_bf3_rm(eng.Wh, eng.Wl, eng.Zh, eng.Zl, 2 * n, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl],
                                                              eng.gU, eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile), iters)
@@ -378,7 +381,7 @@ def roofline_of(e, kern, steps_per_s, world):
             also[k] = {"avg_launch_ms": v["ms"], "bound": "hbm"}
             continue
         pk = BF16_MFMA_PEAK_TFLOPS if "bf3" in k else FP32_MFMA_PEAK_TFLOPS
-        tr, _ = traffic_of(k, world)
+        tr, _ = traffic_of(k, world) if " [" not in k else (None, None)
         also[k] = {"achieved": v["tflops"], "peak": pk, "frac": v["tflops"] / pk, "avg_launch_ms": v["ms"],
                    "algorithmic_flop_per_launch": v["flop"], "traffic": tr}
         if "bf3" in k:

@@ -362,8 +362,9 @@ class CpuOps:
         s = _np(sq).astype(np.float64)
         bwv = float(bw.reshape(-1)[0])
         part = np.zeros((tiles.shape[0], 4), dtype=np.float32)
+        tr, tc = (256, 128) if tile == 256 else (tile, tile)  # tile 256 = 256 rows x 128 columns
         for t, (r0, c0, rlim, clim, fl, *_rest) in enumerate(tiles.tolist()):
-            ri, cj = np.arange(r0, min(r0 + tile, rlim)), np.arange(c0, min(c0 + tile, clim))
+            ri, cj = np.arange(r0, min(r0 + tr, rlim)), np.arange(c0, min(c0 + tc, clim))
             g = zh[ri] @ zh[cj].T + zh[ri] @ zl[cj].T + zl[ri] @ zh[cj].T
             L = np.maximum(s[ri][:, None] + s[cj][None, :] - 2 * g, 0.0)
             K = np.zeros_like(L)

@@ -1191,11 +1191,13 @@ def test_gemm_grouped_split_k_slabs(ops):
         assert np.array_equal(got, again)
 
 
-@pytest.mark.parametrize("n,d,mode", [(1024, 784, 1), (384, 200, 2), (300, 130, 1)])
+@pytest.mark.parametrize("n,d,mode", [(1024, 784, 1), (384, 200, 2), (300, 130, 1), (640, 96, 2)])
 def test_gram_bf3_tile128_equals_tile64(ops, n, d, mode):
-    """The 128x128 split-bf16 Gram kernel against the 64x64 one on the same operands: same block sums (to fp32 summation
-    order), same gradient weights (the hi halves bit-equal; hi + lo to the pair's 2^-16 resolution, since the compiler
-    contracts the epilogue's fp32 expressions differently in the two kernels), same column keys."""
+    """The 128x128 and the 256x128 (loader-wave) split-bf16 Gram kernels against the 64x64 one on the same operands: same
+    block sums (to fp32 summation order), same gradient weights (the hi halves bit-equal; hi + lo to the pair's 2^-16
+    resolution, since the compiler contracts the epilogue's fp32 expressions differently in the kernels), same column keys --
+    ragged row / column counts, mirrored stores of the symmetric blocks and of XY (mode 2), short contractions (d = 96:
+    three K stages, one in the prologue only)."""
     rng = np.random.default_rng(n + d)
     Zf = torch.as_tensor(rng.normal(size=(2 * n, d)).astype(np.float32) * 0.3).cuda()
     S = torch.as_tensor(rng.uniform(0, 2.0 / d, size=(n, d)).astype(np.float32)).cuda()
@@ -1208,7 +1210,7 @@ def test_gram_bf3_tile128_equals_tile64(ops, n, d, mode):
     bw = torch.full((1,), float(d) * 0.2, device="cuda")
     nr, wrow0 = (n, n) if mode == 1 else (2 * n, 0)
     res = {}
-    for tile in (64, 128):
+    for tile in (64, 128, 256):
         tiles = ops.build_tiles(n, mode, tile=tile)
         partial = torch.zeros(tiles.shape[0], 4, device="cuda")
         Wh, Wl = torch.full((nr, kn), 0x7FC0, **i16), torch.full((nr, kn), 0x7FC0, **i16)
@@ -1217,14 +1219,54 @@ def test_gram_bf3_tile128_equals_tile64(ops, n, d, mode):
         stats = torch.zeros(4, dtype=torch.float64, device="cuda")
         ops.mmd_reduce(partial, tiles, stats, True)
         res[tile] = (host(stats), Wh[:, :2 * n].clone(), Wl[:, :2 * n].clone(), colpart.clone())
-    a, b = res[64], res[128]
-    np.testing.assert_allclose(a[0][:3], b[0][:3], rtol=1e-6)
-    assert torch.equal(a[3], b[3])
-    assert not bool((a[1] == 0x7FC0).any()) and not bool((b[1] == 0x7FC0).any()), "part of W left unwritten"
     val = lambda h, l: (h.to(torch.int32) << 16).view(torch.float32).double() + (l.to(torch.int32) << 16).view(torch.float32).double()
-    wa, wb = val(a[1], a[2]), val(b[1], b[2])
-    assert float((wa - wb).abs().max()) <= 5e-5 * float(wa.abs().max())
-    assert float((a[1] != b[1]).double().mean()) < 1e-3  # hi halves differ only where w sits on a bf16 rounding boundary
+    a = res[64]
+    for tile in (128, 256):
+        b = res[tile]
+        np.testing.assert_allclose(a[0][:3], b[0][:3], rtol=1e-6, err_msg=str(tile))
+        assert torch.equal(a[3], b[3])
+        assert not bool((a[1] == 0x7FC0).any()) and not bool((b[1] == 0x7FC0).any()), f"part of W left unwritten ({tile})"
+        wa, wb = val(a[1], a[2]), val(b[1], b[2])
+        assert float((wa - wb).abs().max()) <= 5e-5 * float(wa.abs().max()), tile
+        assert float((a[1] != b[1]).double().mean()) < 1e-3, tile  # hi halves differ only where w sits on a bf16 rounding boundary
+
+
+@pytest.mark.parametrize("n,d,nr_of,splits", [(512, 1000, 1, 2), (300, 130, 2, 1), (1024, 2048, 1, 4), (200, 64, 1, 3)])
+def test_backward_bf3_wide_tiles(ops, n, d, nr_of, splits):
+    """vgan_mmd_backward_bf3_rm on 256 x 128 output tiles (GemmBF3Wide::run_bt: 8 consumer + 4 loader waves, B fragments by
+    transposed LDS reads of Z's row-major images, row sums of W taken by the loader waves from the landed LDS image) against
+    float64 on the same split operands and against the 64-wide kernel: ragged rows, features no multiple of the tile, split-K
+    slabs, gradient rows for the Y half or all rows, multiplier with shift; twice the same bits."""
+    rng = np.random.default_rng(n + d)
+    N = 2 * n
+    kp, kn = (d + 63) // 64 * 64, (N + 63) // 64 * 64
+    dp = (d + 3) // 4 * 4
+    Z = torch.zeros(N, dp, device="cuda")
+    Z[:, :d] = dev(rng.normal(size=(N, d)).astype(np.float32))
+    i16 = dict(dtype=torch.int16, device="cuda")
+    Zh, Zl = torch.zeros(N, kp, **i16), torch.zeros(N, kp, **i16)
+    ops.mmd_bf3_prepare(Z, N, d, Zh, Zl)
+    nr, wrow0 = (n, n) if nr_of == 1 else (N, 0)
+    Wt = dev((rng.normal(size=(nr, N)) * 1e-3).astype(np.float32))
+    Wh, Wl = torch.zeros(nr, kn, **i16), torch.zeros(nr, kn, **i16)
+    hi = Wt.to(torch.bfloat16)
+    Wh[:, :N] = hi.view(torch.int16)
+    Wl[:, :N] = (Wt - hi.float()).to(torch.bfloat16).view(torch.int16)
+    mul = dev(rng.normal(size=(nr, dp)).astype(np.float32))
+    shift = dev(rng.normal(size=(dp,)).astype(np.float32))
+    outs = {}
+    for key, tile in (("wide", 256), ("again", 256), ("t64", 64)):
+        o = torch.full((splits, nr, dp), float("nan"), device="cuda")
+        ops.mmd_backward_bf3_rm(Wh, Wl, Zh, Zl, N, Z, wrow0, nr, d, mul, o[0], splits, nr * dp, mul_shift=shift, tile=tile)
+        outs[key] = o[:, :, :d].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(outs["wide"], outs["again"])
+    w64 = (Wh.view(torch.bfloat16).double() + Wl.view(torch.bfloat16).double())[:, :N]
+    z64 = (Zh.view(torch.bfloat16).double() + Zl.view(torch.bfloat16).double())[:, :d]
+    want = 2.0 * (w64.sum(1, keepdim=True) * Z[wrow0:wrow0 + nr, :d].double() - w64 @ z64) * (mul[:, :d].double() + shift[:d].double())
+    got = outs["wide"].sum(0).double()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((got - outs["t64"].sum(0).double()).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
 def test_two_sample_kernels_and_check_if_myopic(ops):

@@ -15,14 +15,15 @@ def table(n, mode, rank=0, world=1, tile=64):
 
 
 def coverage(n, tabs, nrW, wrow0s, T=64):
-    """Returns (count matrix [2n,2n] of how often the sums see each pair, writes matrix)."""
+    """Returns (count matrix [2n,2n] of how often the sums see each pair, writes matrix).  T = 256: 256-row x 128-column tiles."""
     N = 2 * n
+    TR, TC = (256, 128) if T == 256 else (T, T)
     seen = np.zeros((N, N))
     slot_ok = True
     writes = np.zeros((N, N))
     for tab, wrow0 in zip(tabs, wrow0s):
         for r0, c0, rlim, clim, fl, *_ in tab.tolist():
-            ri, cj = np.arange(r0, min(r0 + T, rlim)), np.arange(c0, min(c0 + T, clim))
+            ri, cj = np.arange(r0, min(r0 + TR, rlim)), np.arange(c0, min(c0 + TC, clim))
             w = 2 if fl & TWICE else 1
             seen[np.ix_(ri, cj)] += 1
             if fl & TWICE:
@@ -39,7 +40,7 @@ def coverage(n, tabs, nrW, wrow0s, T=64):
     return seen, writes, slot_ok
 
 
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [64, 128, 256])
 @pytest.mark.parametrize("n", [1, 63, 64, 100, 128, 500, 1024])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_single_rank_tables(n, mode, tile):
@@ -59,8 +60,8 @@ def test_single_rank_tables(n, mode, tile):
         assert np.array_equal(writes, np.ones((N, N)))
 
 
-@pytest.mark.parametrize("tile", [64, 128])
-@pytest.mark.parametrize("n,world", [(128, 2), (512, 8), (1024, 4), (96, 3)])
+@pytest.mark.parametrize("tile", [64, 128, 256])
+@pytest.mark.parametrize("n,world", [(128, 2), (512, 8), (1024, 4), (96, 3), (2048, 2)])
 def test_row_sharded_tables(n, world, tile):
     tabs = [table(n, 1, r, world, tile) for r in range(world)]
     seen, writes, slot_ok = coverage(n, tabs, None, [0] * world, tile)
@@ -79,8 +80,8 @@ def test_row_sharded_tables(n, world, tile):
         assert ((mir[:, 1] - n >= lo) & (mir[:, 1] - n < hi)).all()
     # the X-X block (sums only) is shared out as its upper triangle: balanced to one tile, half the pairs of "rows x all"
     xx = [int(((t[:, 4] & SLOT) == 0).sum()) for t in tabs]
-    nt = (n + tile - 1) // tile
-    assert sum(xx) == nt * (nt + 1) // 2 and max(xx) - min(xx) <= 1
+    tr, tc = (256, 128) if tile == 256 else (tile, tile)
+    assert sum(xx) == sum(len(range(r, n, tc)) for r in range(0, n, tr)) and max(xx) - min(xx) <= 1
 
 
 def test_bad_arguments():
@@ -89,7 +90,7 @@ def test_bad_arguments():
     assert l.vgan_mmd_build_tiles(64, 3, 0, 1, 64, None, 0) == -1
     assert l.vgan_mmd_build_tiles(64, 2, 0, 2, 64, None, 0) == -1
     assert b"grad_mode 2" in l.vgan_last_error()
-    assert l.vgan_mmd_build_tiles(64, 1, 0, 1, 96, None, 0) == -1  # only 64 and 128 exist
+    assert l.vgan_mmd_build_tiles(64, 1, 0, 1, 96, None, 0) == -1  # only 64, 128 and 256 (= 256 x 128) exist
 
 
 def test_tables_property_random_shapes():
@@ -98,7 +99,7 @@ def test_tables_property_random_shapes():
     from hypothesis import given, settings, strategies as st
 
     @settings(max_examples=40, deadline=None)
-    @given(n=st.integers(1, 700), world=st.sampled_from([1, 1, 2, 3, 4, 8]), tile=st.sampled_from([64, 128]),
+    @given(n=st.integers(1, 700), world=st.sampled_from([1, 1, 2, 3, 4, 8]), tile=st.sampled_from([64, 128, 256]),
            mode=st.sampled_from([0, 1, 2]))
     def check(n, world, tile, mode):
         if world > 1 and (mode == 2 or n < world):

@@ -324,12 +324,13 @@ static uint64_t morton_key(uint32_t r, uint32_t c) {
     for (int b = 0; b < 16; ++b) k |= ((uint64_t)((r >> b) & 1) << (2 * b + 1)) | ((uint64_t)((c >> b) & 1) << (2 * b));
     return k;
 }
-static void order_tiles_for_xcds(int32_t* tiles, int count, int T) {
+static void order_tiles_for_xcds(int32_t* tiles, int count, int tile) {
     constexpr int NX = 8;
+    const int T = tile == 256 ? 256 : tile, TCOL = tile == 256 ? 128 : tile;  // tile 256 = 256 rows x 128 columns
     std::vector<std::array<int32_t, VGAN_TILE_INTS>> v(count);
     for (int t = 0; t < count; ++t) std::memcpy(v[t].data(), tiles + (size_t)t * VGAN_TILE_INTS, sizeof(int32_t) * VGAN_TILE_INTS);
-    std::stable_sort(v.begin(), v.end(), [T](const auto& a, const auto& b) {
-        return morton_key(a[0] / T, a[1] / T) < morton_key(b[0] / T, b[1] / T);
+    std::stable_sort(v.begin(), v.end(), [T, TCOL](const auto& a, const auto& b) {
+        return morton_key(a[0] / T, a[1] / TCOL) < morton_key(b[0] / T, b[1] / TCOL);
     });
     const int q = count / NX, r = count % NX;
     int src = 0;
@@ -341,7 +342,7 @@ static void order_tiles_for_xcds(int32_t* tiles, int count, int T) {
 
 // XCD-aware order (see order_tiles_for_xcds) for a table the caller has filtered or concatenated itself
 extern "C" int vgan_mmd_order_tiles(int32_t* tiles, int count, int tile) {
-    if (tiles == nullptr || count < 0 || (tile != 64 && tile != 128)) {
+    if (tiles == nullptr || count < 0 || (tile != 64 && tile != 128 && tile != 256)) {
         set_error("vgan_mmd_order_tiles: bad argument");
         return VGAN_ERR_ARG;
     }
@@ -356,11 +357,15 @@ extern "C" const char* vgan_last_error(void) { return g_err; }
 // the XY block is laid out with rows in the Y half and columns in the X half so that Wg ([n,2n],
 // wrow0 = n) needs no transposed store for it.  Row-sharded ranks cover (own rows) x (all columns).
 extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int tile, int32_t* out, int cap) {
-    if (n <= 0 || grad_mode < 0 || grad_mode > 2 || world < 1 || rank < 0 || rank >= world || (tile != 64 && tile != 128)) {
+    if (n <= 0 || grad_mode < 0 || grad_mode > 2 || world < 1 || rank < 0 || rank >= world || (tile != 64 && tile != 128 && tile != 256)) {
         set_error("vgan_mmd_build_tiles: bad argument");
         return -1;
     }
-    const int T = tile;
+    // tile 64 / 128: square tiles; tile 256: 256 rows x 128 columns (GemmBF3Wide).  A symmetric block keeps the upper triangle:
+    // tiles right of the T x T square on the diagonal are counted twice and mirrored, the square's own tiles (one for a square
+    // tile on the diagonal, two side by side for 256 x 128) are computed in full -- a diagonal 64- or 128-wide tile is its own
+    // mirror image, which is the same statement.
+    const int T = tile == 256 ? 256 : tile, TC = tile == 256 ? 128 : tile;
     int count = 0;
     auto emit = [&](int r0, int c0, int rlim, int clim, int flags) {
         if (out != nullptr && count < cap) {
@@ -372,14 +377,15 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
     if (world == 1) {
         // XX: upper triangle; gradient rows only when grad_mode == 2
         for (int r = 0; r < n; r += T)
-            for (int c = r; c < n; c += T) {
-                int fl = 0 | (c > r ? VGAN_TF_TWICE : 0);
-                if (grad_mode == 2) fl |= VGAN_TF_STORE | (c > r ? VGAN_TF_MIRROR : 0);
+            for (int c = r; c < n; c += TC) {
+                const bool off = c >= r + T;
+                int fl = 0 | (off ? VGAN_TF_TWICE : 0);
+                if (grad_mode == 2) fl |= VGAN_TF_STORE | (off ? VGAN_TF_MIRROR : 0);
                 emit(r, c, n, n, fl);
             }
         // XY: rows in Y, columns in X (full block)
         for (int r = 0; r < n; r += T)
-            for (int c = 0; c < n; c += T) {
+            for (int c = 0; c < n; c += TC) {
                 int fl = 1 | VGAN_TF_NEG;
                 if (grad_mode >= 1) fl |= VGAN_TF_STORE;
                 if (grad_mode == 2) fl |= VGAN_TF_MIRROR;
@@ -387,9 +393,10 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
             }
         // YY: upper triangle
         for (int r = 0; r < n; r += T)
-            for (int c = r; c < n; c += T) {
-                int fl = 2 | (c > r ? VGAN_TF_TWICE : 0);
-                if (grad_mode >= 1) fl |= VGAN_TF_STORE | (c > r ? VGAN_TF_MIRROR : 0);
+            for (int c = r; c < n; c += TC) {
+                const bool off = c >= r + T;
+                int fl = 2 | (off ? VGAN_TF_TWICE : 0);
+                if (grad_mode >= 1) fl |= VGAN_TF_STORE | (off ? VGAN_TF_MIRROR : 0);
                 emit(n + r, n + c, 2 * n, 2 * n, fl);
             }
     } else {
@@ -405,24 +412,24 @@ extern "C" int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, i
         // "own rows x all columns".
         int k = 0;
         for (int r = 0; r < n; r += T)
-            for (int c = r; c < n; c += T, ++k)
-                if (k % world == rank) emit(r, c, n, n, 0 | (c > r ? VGAN_TF_TWICE : 0));
+            for (int c = r; c < n; c += TC, ++k)
+                if (k % world == rank) emit(r, c, n, n, 0 | (c >= r + T ? VGAN_TF_TWICE : 0));
         for (int r = lo; r < hi; r += T)
-            for (int c = 0; c < n; c += T) emit(n + r, c, n + hi, n, 1 | VGAN_TF_NEG | (grad_mode ? VGAN_TF_STORE : 0));
+            for (int c = 0; c < n; c += TC) emit(n + r, c, n + hi, n, 1 | VGAN_TF_NEG | (grad_mode ? VGAN_TF_STORE : 0));
         // YY: own rows x all columns; inside the rank's own diagonal block the upper triangle with mirrored stores does (both
         // halves of a mirrored pair are rows of this rank), when the block is a whole number of tiles on the tile grid
         const bool tri = lo % T == 0 && hi % T == 0;
         for (int r = lo; r < hi; r += T)
-            for (int c = 0; c < n; c += T) {
+            for (int c = 0; c < n; c += TC) {
                 const bool diag = tri && c >= lo && c < hi;
                 if (diag && c < r) continue;
                 int fl = 2 | (grad_mode ? VGAN_TF_STORE : 0);
-                if (diag && c > r) fl |= VGAN_TF_TWICE | (grad_mode ? VGAN_TF_MIRROR : 0);
+                if (diag && c >= r + T) fl |= VGAN_TF_TWICE | (grad_mode ? VGAN_TF_MIRROR : 0);
                 emit(n + r, n + c, n + hi, 2 * n, fl);
             }
     }
     if (out != nullptr && count > cap) return -1;
-    if (out != nullptr) order_tiles_for_xcds(out, count, T);
+    if (out != nullptr) order_tiles_for_xcds(out, count, tile);
     return count;
 }
 

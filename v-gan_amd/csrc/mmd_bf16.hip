@@ -14,6 +14,7 @@
 // GemmBF3::run_bt), which hand each lane the 8 consecutive k (= Z rows) its B fragment needs.  The transposed copies
 // (ZTh, ZTl) of round 1 are written only on request (vgan_mmd_backward_bf3, kept for measurement).
 #include "gemm_bf3.hpp"
+#include "gemm_bf3w.hpp"
 #include "mmd_common.hpp"
 #include "mmd_xx.hpp"
 
@@ -299,6 +300,146 @@ __global__ __launch_bounds__(512, 2) void mmd_gram_bf3_big_kernel(const unsigned
             make_float4(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])), 0.f, 0.f, 0.f);
 }
 
+
+// ---- the same Gram tile + epilogue on 256 x 128 tiles (GemmBF3Wide: 768 threads = 8 consumer + 4 loader waves) -----------
+// Tile tables built with tile = 256 (vgan_mmd_build_tiles): rows step 256, columns step 128; the symmetric blocks keep their
+// mirrored / counted-twice tiles only OUTSIDE the 256 x 256 squares on the diagonal, whose two tiles are computed in full.
+__global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigned short* __restrict__ Zh, const unsigned short* __restrict__ Zl,
+                                                                   int kp, const float* __restrict__ sq, int n,
+                                                                   const float* __restrict__ bw_ptr, const TileDesc* __restrict__ tiles,
+                                                                   int ntiles, unsigned short* __restrict__ Wh,
+                                                                   unsigned short* __restrict__ Wl, int ldw, int wrow0,
+                                                                   float* __restrict__ partial, ColmaxJob cj) {
+    using G = GemmBF3Wide;
+    constexpr int LDT = 132, LDM = 260;  // epilogue images Wt[256][LDT] (direct) and WtT[128][LDM] (mirrored), one at a time
+    static_assert(256 * LDT * 4 <= G::kLdsBytes && 128 * LDM * 4 <= G::kLdsBytes, "epilogue images reuse the stage buffers");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ float red[12];
+    if ((int)blockIdx.x >= ntiles) {
+        const int cb = blockIdx.x - ntiles;
+        colmax_partial_body<12>(cj.S, cj.lds, cj.row_offset, cj.part, cj.n, cj.d, cj.from_softmax, cb % cj.nbx, cb / cj.nbx);
+        return;
+    }
+    const TileDesc td = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool cons = !G::is_loader();
+    // epilogue operands requested before the main loop (see mmd_gram_bf3_kernel); loader threads clamp to the tile's corner
+    const float bw = bw_ptr[0];
+    float sjv[4], siv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sjv[j] = sq[min(td.c0 + (cons ? G::sub_col(j) : 0), td.clim - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) siv[i][r] = sq[min(td.r0 + (cons ? G::sub_row(i, r) : 0), td.rlim - 1)];
+    f32x4w acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    G::run<false>(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, acc);
+
+    const float c2 = -1.4426950408889634f / (4.f * bw);
+    const float wscale = -((td.flags & VGAN_TF_NEG) ? -1.f : 1.f) * 2.f / ((float)n * (float)n * bw);
+    const bool store = (td.flags & VGAN_TF_STORE) && Wh != nullptr;
+    const bool mirror = store && (td.flags & VGAN_TF_MIRROR);
+    float ksum = 0.f;
+    if (cons) {  // acc <- gradient weight w, ksum <- kernel sum of the valid pairs
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (td.r0 + G::sub_row(i, r) < td.rlim) && (td.c0 + G::sub_col(j) < td.clim);
+                    const float L = fmaxf(siv[i][r] + sjv[j] - 2.f * acc[i][j][r], 0.f);
+                    const float t = __builtin_amdgcn_exp2f(L * c2);
+                    const float t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+                    ksum += ok ? ((t + t2) + (t4 + t8)) + t16 : 0.f;
+                    acc[i][j][r] = wscale * (((0.25f * t + 0.5f * t2) + (t4 + 2.f * t8)) + 4.f * t16);
+                }
+    }
+    if (store) {  // uniform per workgroup
+        lds_f* Wt = (lds_f*)(float*)lds;
+        // 16 consecutive weights of one output row -> hi / lo bf16 images (two 16-byte stores each when the run is whole)
+        auto emit = [&](const float (&w)[16], long rowo, int c_first, int c_lim) {
+            unsigned hp[8], lp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned short h0, l0, h1, l1;
+                split_bf16(w[2 * e], h0, l0);
+                split_bf16(w[2 * e + 1], h1, l1);
+                hp[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                lp[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+            if (c_first + 15 < c_lim) {
+                uint4* dh = reinterpret_cast<uint4*>(Wh + rowo + c_first);
+                uint4* dl = reinterpret_cast<uint4*>(Wl + rowo + c_first);
+                dh[0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                dh[1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+                dl[0] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+                dl[1] = make_uint4(lp[4], lp[5], lp[6], lp[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (c_first + e < c_lim) {
+                        Wh[rowo + c_first + e] = (unsigned short)(hp[e >> 1] >> (16 * (e & 1)));
+                        Wl[rowo + c_first + e] = (unsigned short)(lp[e >> 1] >> (16 * (e & 1)));
+                    }
+            }
+        };
+        float w[16];
+        if (cons) {  // direct image Wt[row][col]: for a fixed (i, j, r) the 64 lanes hit 64 different banks (4 * LDT = 16 mod 64)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Wt[G::sub_row(i, r) * LDT + G::sub_col(j)] = acc[i][j][r];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 256 * 8; t += G::NTH) {  // all twelve waves store: row r0 + line, columns c0 + 16 q ..
+            const int line = t >> 3, q16 = 16 * (t & 7);
+            if (td.r0 + line < td.rlim && td.c0 + q16 < td.clim) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 v = *(const lds_f4*)(Wt + line * LDT + q16 + 4 * e);
+                    w[4 * e] = v[0]; w[4 * e + 1] = v[1]; w[4 * e + 2] = v[2]; w[4 * e + 3] = v[3];
+                }
+                emit(w, (long)(td.r0 + line - wrow0) * ldw, td.c0 + q16, td.clim);
+            }
+        }
+        if (mirror) {  // mirrored image WtT[col][row]: a lane's four r are four consecutive rows -> one 16-byte LDS store per block
+            __syncthreads();
+            if (cons) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *(lds_f4*)(Wt + G::sub_col(j) * LDM + G::sub_row(i, 0)) = f32x4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < 128 * 16; t += G::NTH) {  // row c0 + line of W, columns r0 + 16 q ..
+                const int line = t >> 4, q16 = 16 * (t & 15);
+                if (td.c0 + line < td.clim && td.r0 + q16 < td.rlim) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 v = *(const lds_f4*)(Wt + line * LDM + q16 + 4 * e);
+                        w[4 * e] = v[0]; w[4 * e + 1] = v[1]; w[4 * e + 2] = v[2]; w[4 * e + 3] = v[3];
+                    }
+                    emit(w, (long)(td.c0 + line - wrow0) * ldw, td.r0 + q16, td.rlim);
+                }
+            }
+        }
+    }
+    ksum = wave_sum(ksum);
+    if (lane == 0) red[wave] = ksum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        reinterpret_cast<float4*>(partial)[blockIdx.x] =
+            make_float4(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])), 0.f, 0.f, 0.f);
+}
+
 // ---- backward: out = 2 (rowsum(W) z - W . Z) * mul, W = Wh + Wl [nr, kn], Z^T = ZTh + ZTl [kp, kn] -------------
 // RM: the B operand is Z's ROW-MAJOR split images (Zh, Zl [zrows, kp], what the Gram reads) instead of the transposed copies
 // (ZTh, ZTl [kp, kn]); `kn` is then the padded contraction length (columns of W) and `brows` the rows of Zh that exist.
@@ -430,6 +571,66 @@ __global__ __launch_bounds__(512, 2) void mmd_backward_bf3_big_kernel(const unsi
     }
 }
 
+
+// ---- backward on 256 x 128 output tiles (GemmBF3Wide::run_bt: B = Z's row-major split images; row sums from the loader waves)
+__global__ __launch_bounds__(768, 3) void mmd_backward_bf3_wide_kernel(const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
+                                                                       int ldw, const unsigned short* __restrict__ Bh,
+                                                                       const unsigned short* __restrict__ Bl, int kn, int ldb, int brows,
+                                                                       const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
+                                                                       int ptiles, const float* __restrict__ mul, int ldmul,
+                                                                       const float* __restrict__ mul_shift, float* __restrict__ out, int ldo,
+                                                                       int kchunk, long slab_stride, int nb_cols, vgan_finalize_job job) {
+    using G = GemmBF3Wide;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ float rs[256];
+    const int gx = ptiles, gy = (nr + 255) / 256, total = gx * gy;
+    if ((int)blockIdx.x >= total) {
+        if (blockIdx.y == 0) finalize_body(job);
+        return;
+    }
+    // XCD-aware order as in the other backward kernels: down 4 row panels, then the next feature panel
+    const int xcd = blockIdx.x % 8, kidx = blockIdx.x / 8;
+    const int q = total / 8, r8 = total % 8;
+    const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + kidx;
+    const int band = t / (4 * gx), rem = t - band * 4 * gx;
+    const int rows_in_band = min(4, gy - band * 4);
+    const int m0 = (band * 4 + rem % rows_in_band) * 256, n0 = (rem / rows_in_band) * 128;
+    const int k0 = blockIdx.y * kchunk, klen = min(kchunk, kn - k0);
+    out += blockIdx.y * slab_stride;
+    f32x4w acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    if (klen > 0)
+        G::run_bt<true>(Wh + k0, Wl + k0, ldw, Bh + (long)k0 * ldb, Bl + (long)k0 * ldb, ldb, nb_cols, brows - k0, m0, n0, nr, klen, lds, acc, rs);
+    if (G::is_loader()) return;  // (no barrier below)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + G::sub_col(j);
+        if (col >= p) continue;
+        const float mshift = mul_shift != nullptr ? mul_shift[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float z_pre[4], m_pre[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowc = min(m0 + G::sub_row(i, r), nr - 1);
+                z_pre[r] = Z[(long)(wrow0 + rowc) * ldz + col];
+                m_pre[r] = mul != nullptr ? mul[(long)rowc * ldmul + col] + mshift : 1.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = G::sub_row(i, r), row = m0 + lrow;
+                if (row < nr) {
+                    const float v = klen > 0 ? 2.f * (rs[lrow] * z_pre[r] - acc[i][j][r]) : 0.f;
+                    out[(long)row * ldo + col] = v * m_pre[r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace vgan
 
 using namespace vgan;
@@ -460,8 +661,14 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
         cj = ColmaxJob{S, reinterpret_cast<unsigned long long*>(colpart), lds, row_offset, nrows, d, from_softmax, (d + 63) / 64};
         extra = cj.nbx * ((nrows + kColChunkRows - 1) / kColChunkRows);
     }
-    VGAN_CHECK_ARG(tile == 64 || tile == 128);
-    if (tile == 128)
+    VGAN_CHECK_ARG(tile == 64 || tile == 128 || tile == 256);
+    if (tile == 256) {  // 256 x 128 tiles: 768-thread workgroups holding all but 16 KB of a CU's LDS
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_gram_bf3_wide_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, GemmBF3Wide::kLdsBytes);
+        VGAN_CHECK_ARG(attr == hipSuccess);
+        hipLaunchKernelGGL(mmd_gram_bf3_wide_kernel, dim3(ntiles + extra), dim3(GemmBF3Wide::NTH), GemmBF3Wide::kLdsBytes, (hipStream_t)stream, Zh,
+                           Zl, kp, sq, n, bw, reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
+    } else if (tile == 128)
         hipLaunchKernelGGL(mmd_gram_bf3_big_kernel, dim3(ntiles + extra), dim3(512), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
                            reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
     else
@@ -474,7 +681,10 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
 // the tile edge vgan_mmd_backward_bf3 runs for this shape: 128-wide tiles (half the L2 -> LDS bytes per flop) once they
 // fill the chip at least twice over, unless the caller forces one
 extern "C" int vgan_mmd_backward_bf3_tile(int nr, int p, int splits, int tile) {
-    if (tile == 64 || tile == 128) return tile;
+    if (tile == 64 || tile == 128 || tile == 256) return tile;
+    // 256 x 128 tiles (GemmBF3Wide, row-major B only: the caller falls back to 128 for transposed images) once they fill the chip
+    const int wide_tiles = ((p + 127) / 128) * ((nr + 255) / 256);
+    if (nr >= 256 && wide_tiles * splits >= 256) return 256;
     const int big_tiles = ((p + 127) / 128) * ((nr + 127) / 128);
     return big_tiles * splits >= 512 ? 128 : 64;
 }
@@ -488,7 +698,7 @@ static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, i
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
     VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(Bh) && aligned16(Bl) && ldw % 8 == 0);
     VGAN_CHECK_ARG(splits >= 1 && splits <= 64 && (splits == 1 || slab_stride >= (int64_t)nr * ldo));
-    VGAN_CHECK_ARG((tile == 0 || tile == 64 || tile == 128) && (mul_shift == nullptr || mul != nullptr) && (!rm || zrows > 0));
+    VGAN_CHECK_ARG((tile == 0 || tile == 64 || tile == 128 || tile == 256) && (mul_shift == nullptr || mul != nullptr) && (!rm || zrows > 0));
     const int kchunk = ((kn / 64 + splits - 1) / splits) * 64;
     const int ldb = rm ? kp : kn;
     vgan_finalize_job job{};
@@ -505,7 +715,20 @@ static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, i
         xx = XXJob{j.Dh, j.Dl, j.dsq, nullptr, nullptr, reinterpret_cast<const TileDesc*>(j.tiles), j.bw, j.partial, j.ldd, 1, 0, j.ntiles, 0};
     }
     const int nfin = finalize != nullptr ? 1 : 0;
-    if (vgan_mmd_backward_bf3_tile(nr, p, splits, tile) == 128) {
+    int edge = vgan_mmd_backward_bf3_tile(nr, p, splits, tile);
+    if (edge == 256 && !rm) edge = 128;
+    if (edge == 256) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_backward_bf3_wide_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, GemmBF3Wide::kLdsBytes);
+        VGAN_CHECK_ARG(attr == hipSuccess);
+        const int pt = (p + 127) / 128;
+        dim3 grid(pt * ((nr + 255) / 256) + nfin, splits);
+        hipLaunchKernelGGL(mmd_backward_bf3_wide_kernel, grid, dim3(GemmBF3Wide::NTH), GemmBF3Wide::kLdsBytes, st, Wh, Wl, ldw, Bh, Bl, kn, ldb,
+                           zrows, Z, ldz, wrow0, nr, p, pt, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, kp, job);
+        VGAN_CHECK_LAUNCH();
+        return VGAN_OK;
+    }
+    if (edge == 128) {
         const int pt = (p + 127) / 128;
         dim3 grid(pt * ((nr + 127) / 128) + (finalize != nullptr ? 1 : 0), splits);
         if (rm)

@@ -84,13 +84,15 @@ __device__ __forceinline__ void colmax_partial_body(const float* __restrict__ S,
     if (j < d) {
         // all loads of the chunk are issued before the first compare (the blocks that run this inside the Gram launch are
         // latency-bound); rows past the end are clamped to the last row, whose key they merely repeat
-        constexpr int PER = kColChunkRows / NW;
+        // (NW need not divide the chunk: a wave's surplus turn repeats the chunk's last row, and a max does not mind)
+        constexpr int PER = (kColChunkRows + NW - 1) / NW;
         float sv[PER];
 #pragma unroll
-        for (int e = 0; e < PER; ++e) sv[e] = S[(long)min(r0 + wave + e * NW, n - 1) * lds + j];
+        for (int e = 0; e < PER; ++e) sv[e] = S[(long)min(r0 + min(wave + e * NW, kColChunkRows - 1), n - 1) * lds + j];
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const unsigned long long k = colkey_pack(sv[e] < tau ? sv[e] : 1.0f, (unsigned)(row_offset + min(r0 + wave + e * NW, n - 1)));
+            const unsigned long long k = colkey_pack(sv[e] < tau ? sv[e] : 1.0f,
+                                                     (unsigned)(row_offset + min(r0 + min(wave + e * NW, kColChunkRows - 1), n - 1)));
             best = k > best ? k : best;
         }
     }

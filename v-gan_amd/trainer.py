@@ -297,6 +297,12 @@ class NoKLStepEngine:
         if self.bf3 and nl % 128 == 0 and want in ("auto", "128"):
             if want == "128" or len(ops.build_tiles(n, 1, rank, world, device=self.dev, tile=128)) >= 512:
                 self.gram_tile = 128
+        # ... and a 256 x 128 variant with dedicated loader waves (csrc/gemm_bf3w.hpp: 3/4 of the fill bytes per flop, three
+        # K stages in LDS, v_mfma_f32_16x16x32_bf16; main loop +17-19 % over the 128 x 128 one on warm operands), used once ITS
+        # table fills the chip twice over (c4: 1 056 tiles, c5: 4 160)
+        if self.bf3 and nl % 256 == 0 and want in ("auto", "256"):
+            if want == "256" or len(ops.build_tiles(n, 1, rank, world, device=self.dev, tile=256)) >= 512:
+                self.gram_tile = 256
         # Overlap of the step's tail with the only work of the NEXT step that needs no updated parameter: the X half of its
         # operand (gather, centre, split) and the X-X tiles of its Gram, which feed nothing but the reported loss.  They run on
         # a side stream that forks right after the MMD backward launch (whose riding step tail has advanced the batch cursor)
@@ -356,7 +362,7 @@ class NoKLStepEngine:
             # two), so a first part of 3 x 256 + 4 tiles pays a fourth round for the four (c5, 8 ranks: 772 + 484 tiles, 352 + 198
             # us against ~100 us per round).  The boundary may move DOWN freely -- the second launch runs after the all-gather and
             # can take any tile -- so the tail of the first part goes over when the second part has free slots for it.
-            slots = 256 if self.gram_tile == 128 else (512 if self.bf3 else 1024)  # (fp32 kernel: 36 KB of LDS, four workgroups per CU)
+            slots = 256 if self.gram_tile >= 128 else (512 if self.bf3 else 1024)  # (fp32 kernel: 36 KB of LDS, four workgroups per CU)
             tail, second = self.n_main % slots, self.tiles.shape[0] - self.n_main
             if 0 < tail < self.n_main and -(-(second + tail) // slots) == -(-second // slots):
                 self.n_main -= tail
