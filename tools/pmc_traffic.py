@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = ["mmd_gram_kernel", "mmd_backward_kernel", "mmd_gram_bf3_kernel", "mmd_backward_bf3_kernel", "mmd_gram_bf3_big_kernel",
-           "mmd_backward_bf3_big_kernel", "bf3_prepare_kernel", "mask_forward_bf3_kernel"]
+           "mmd_backward_bf3_big_kernel", "mmd_gram_bf3_wide_kernel", "mmd_backward_bf3_wide_kernel", "bf3_prepare_kernel", "mask_forward_bf3_kernel"]
 
 
 def fold(d):

@@ -117,7 +117,7 @@ struct WideT {
 typedef WideT<> Wide;
 
 template <class G>
-__global__ __launch_bounds__(512, 2) void k_wide(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out,
+__global__ __launch_bounds__(512, 2) void k_wide(const unsigned short* Zh, const unsigned short* Zl, int kp, int ld, int N, int tiles_per_row, float* out,
                                                 float* tile0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-aware order: block b runs on XCD b % 8; each XCD walks its own contiguous chunk of 4 x 8 tile blocks, so the 32 tiles
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void k_wide(const unsigned short* Zh, const
     const int blk = t / 32, in = t % 32, bpr = tiles_per_row / 8;
     const int r0 = ((blk / bpr) * 4 + in / 8) * 256, c0 = ((blk % bpr) * 8 + in % 8) * 128;
     f32x4v acc[4][4];
-    G::run(Zh, Zl, kp, Zh, Zl, kp, r0, c0, N, N, kp, lds, acc);
+    G::run(Zh, Zl, ld, Zh, Zl, ld, r0, c0, N, N, kp, lds, acc);
     float s = 0;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
     out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
@@ -253,13 +253,13 @@ struct WideLW {
     }
 };
 
-__global__ __launch_bounds__(768, 3) void k_lw(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out, float* tile0) {
+__global__ __launch_bounds__(768, 3) void k_lw(const unsigned short* Zh, const unsigned short* Zl, int kp, int ld, int N, int tiles_per_row, float* out, float* tile0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int per = gridDim.x / 8, t = (blockIdx.x % 8) * per + blockIdx.x / 8;
     const int blk = t / 32, in = t % 32, bpr = tiles_per_row / 8;
     const int r0 = ((blk / bpr) * 4 + in / 8) * 256, c0 = ((blk % bpr) * 8 + in % 8) * 128;
     f32x4v acc[4][4];
-    WideLW::run(Zh, Zl, kp, Zh, Zl, kp, r0, c0, N, N, kp, lds, acc);
+    WideLW::run(Zh, Zl, ld, Zh, Zl, ld, r0, c0, N, N, kp, lds, acc);
     if (threadIdx.x >= 512) return;
     float s = 0;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(768, 3) void k_lw(const unsigned short* Zh, const u
     }
 }
 
-__global__ __launch_bounds__(512, 2) void k_big(const unsigned short* Zh, const unsigned short* Zl, int kp, int N, int tiles_per_row, float* out) {
+__global__ __launch_bounds__(512, 2) void k_big(const unsigned short* Zh, const unsigned short* Zl, int kp, int ld, int N, int tiles_per_row, float* out) {
     using G = GemmBF3Big;
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
     const int per = gridDim.x / 8, t = (blockIdx.x % 8) * per + blockIdx.x / 8;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void k_big(const unsigned short* Zh, const 
     const int r0 = ((blk / bpr) * 4 + in / 8) * 128, c0 = ((blk % bpr) * 8 + in % 8) * 128;
     f32x16 acc[2];
     for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    G::run<false>(Zh, Zl, kp, Zh, Zl, kp, r0, c0, N, N, kp, lds, acc);
+    G::run<false>(Zh, Zl, ld, Zh, Zl, ld, r0, c0, N, N, kp, lds, acc);
     float s = 0;
     for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
@@ -288,11 +288,11 @@ __global__ __launch_bounds__(512, 2) void k_big(const unsigned short* Zh, const 
 static float bf(unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main(int argc, char** argv) {
-    const int N = argc > 1 ? atoi(argv[1]) : 8192, kp = argc > 2 ? atoi(argv[2]) : 4096;
+    const int N = argc > 1 ? atoi(argv[1]) : 8192, kp = argc > 2 ? atoi(argv[2]) : 4096, pad = argc > 3 ? atoi(argv[3]) : 0, ld = kp + pad;
     const int tprW = N / 128, ntW = (N / 256) * tprW, tprB = N / 128, ntB = tprB * tprB;
     unsigned short *Zh, *Zl; float *out, *tile0;
-    hipMalloc(&Zh, (size_t)N * kp * 2); hipMalloc(&Zl, (size_t)N * kp * 2); hipMalloc(&out, (size_t)ntB * 512 * 4); hipMalloc(&tile0, 256 * 128 * 4);
-    std::vector<unsigned short> hh((size_t)N * kp), hl((size_t)N * kp);
+    hipMalloc(&Zh, (size_t)N * ld * 2); hipMalloc(&Zl, (size_t)N * ld * 2); hipMalloc(&out, (size_t)ntB * 512 * 4); hipMalloc(&tile0, 256 * 128 * 4);
+    std::vector<unsigned short> hh((size_t)N * ld), hl((size_t)N * ld);
     for (auto& v : hh) v = 0x3F00 + rand() % 128 + ((rand() & 1) << 15);
     for (auto& v : hl) v = 0x3B00 + rand() % 128;
     hipMemcpy(Zh, hh.data(), hh.size() * 2, hipMemcpyHostToDevice);
@@ -304,7 +304,7 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<false, true, false>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<true, false, false>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     // correctness of tile 1 (rows 0..255, columns 128..255)
-    hipLaunchKernelGGL(k_wide<Wide>, dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, tile0);
+    hipLaunchKernelGGL(k_wide<Wide>, dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, tile0);
     std::vector<float> t0(256 * 128);
     hipMemcpy(t0.data(), tile0, t0.size() * 4, hipMemcpyDeviceToHost);
     double worst = 0, big = 0;
@@ -312,8 +312,8 @@ int main(int argc, char** argv) {
         for (int j = 0; j < 128; j += 11) {
             double s = 0;
             for (int k = 0; k < kp; ++k) {
-                const double ah = bf(hh[(size_t)i * kp + k]), al = bf(hl[(size_t)i * kp + k]);
-                const double bh = bf(hh[(size_t)(128 + j) * kp + k]), bl = bf(hl[(size_t)(128 + j) * kp + k]);
+                const double ah = bf(hh[(size_t)i * ld + k]), al = bf(hl[(size_t)i * ld + k]);
+                const double bh = bf(hh[(size_t)(128 + j) * ld + k]), bl = bf(hl[(size_t)(128 + j) * ld + k]);
                 s += al * bh + ah * bl + ah * bh;
             }
             worst = fmax(worst, fabs(s - t0[i * 128 + j]));
@@ -321,7 +321,7 @@ int main(int argc, char** argv) {
         }
     printf("wide tile check: max |err| %.3e (largest |value| %.3e) %s\n", worst, big, worst <= 2e-5 * big + 1e-3 ? "OK" : "MISMATCH");
     hipMemset(tile0, 0, 256 * 128 * 4);
-    hipLaunchKernelGGL(k_lw, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, tile0);
+    hipLaunchKernelGGL(k_lw, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, tile0);
     std::vector<float> t1(256 * 128);
     hipMemcpy(t1.data(), tile0, t1.size() * 4, hipMemcpyDeviceToHost);
     printf("loader-wave variant equals the plain wide loop bit for bit: %s\n", memcmp(t0.data(), t1.data(), t0.size() * 4) == 0 ? "yes" : "NO");
@@ -331,13 +331,13 @@ int main(int argc, char** argv) {
         for (int which = 0; which < 7; ++which) {
             auto launch = [&]() {
                 float* nul = nullptr;
-                if (which == 0) hipLaunchKernelGGL(k_big, dim3(ntB), dim3(512), 0, 0, Zh, Zl, kp, N, tprB, out);
-                else if (which == 1) hipLaunchKernelGGL(k_wide<Wide>, dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, nul);
-                else if (which == 2) hipLaunchKernelGGL((k_wide<WideT<false, true, true>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, nul);
-                else if (which == 3) hipLaunchKernelGGL((k_wide<WideT<true, false, true>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, nul);
-                else if (which == 4) hipLaunchKernelGGL((k_wide<WideT<false, true, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, nul);
-                else if (which == 5) hipLaunchKernelGGL((k_wide<WideT<true, false, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, nul);
-                else hipLaunchKernelGGL(k_lw, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, N, tprW, out, nul);
+                if (which == 0) hipLaunchKernelGGL(k_big, dim3(ntB), dim3(512), 0, 0, Zh, Zl, kp, ld, N, tprB, out);
+                else if (which == 1) hipLaunchKernelGGL(k_wide<Wide>, dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else if (which == 2) hipLaunchKernelGGL((k_wide<WideT<false, true, true>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else if (which == 3) hipLaunchKernelGGL((k_wide<WideT<true, false, true>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else if (which == 4) hipLaunchKernelGGL((k_wide<WideT<false, true, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else if (which == 5) hipLaunchKernelGGL((k_wide<WideT<true, false, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else hipLaunchKernelGGL(k_lw, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
             };
             for (int i = 0; i < 10; ++i) launch();
             hipEventRecord(e0);

@@ -101,16 +101,29 @@ struct GemmBF3Wide {
     // sum over the stage's 32 k of (Ah + Al)[row]: the loader's lane reads its row's four chunks of both parts (any order:
     // a sum) -- conflict-free, 16 consecutive rows of one position per lane group
     __device__ static __forceinline__ float row_part(const lds_c* st, int row, float s) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+        // eight independent chains, dependent instructions eight apart (v_dot2c_f32_bf16 accumulates in place)
+        u32x4 h[4], l[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const u32x4 h = *(const lds_u4*)(st + row * 64 + 16 * c), l = *(const lds_u4*)(st + PA + row * 64 + 16 * c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s += __uint_as_float(h[e] << 16) + __uint_as_float(h[e] & 0xFFFF0000u);
-                s += __uint_as_float(l[e] << 16) + __uint_as_float(l[e] & 0xFFFF0000u);
-            }
+            h[c] = *(const lds_u4*)(st + row * 64 + 16 * c);
+            l[c] = *(const lds_u4*)(st + PA + row * 64 + 16 * c);
         }
-        return s;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // (each dword passes through an empty asm: hipcc 7.2 otherwise folds the four element extracts of a vector into
+                //  ONE source register for this builtin -- the "wrong sums" noted at GemmBF3Big::frag_sum)
+                unsigned he = h[c][e], le = l[c][e];
+                asm volatile("" : "+v"(he), "+v"(le));
+                a[2 * c] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, he), ones, a[2 * c], false);
+                a[2 * c + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, le), ones, a[2 * c + 1], false);
+            }
+        const float s2 = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        return s + s2;
     }
 
     // The loader wave's whole life inside the main loop.  SIDE_A: rs[256] (LDS floats) = sum_k A[m0 + m, k].

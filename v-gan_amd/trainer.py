@@ -255,6 +255,10 @@ class NoKLStepEngine:
         # (a slab keeps at least one 64-deep K tile: at c1 -- two output tiles, K = 256 -- four slabs of one K tile beat one
         #  workgroup looping over four, 23.5 k vs 21.9 k steps/s; 8 and 16 slabs at c2: the consumer's slab loop costs more than it saves)
         auto_splits = max(2 if self.bf3 else 1, min(4, 256 // max(out_tiles, 1), max(1, (2 * n) // 64)))
+        # (the 256 x 128 loader-wave tiles of c4 / c5 fill the chip without slabs: c5 3.27 ms with two slabs, 3.16 with one)
+        rm = self.front_sharded or os.environ.get("VGAN_BWD_OPERAND", "rowmajor") != "transposed"  # (self.rm_backward, set below)
+        if self.bf3 and rm and self.bwd_tile in (0, 256) and ops.mmd_backward_bf3_tile(nl, d, 1, self.bwd_tile) == 256:
+            auto_splits = 1
         self.bsplits = max(1, int(os.environ.get("VGAN_BWD_SPLITS", str(auto_splits))))
         self.gU_slabs = torch.zeros(self.bsplits, nl, dp, **f32)
         self.gU = self.gU_slabs[0]
