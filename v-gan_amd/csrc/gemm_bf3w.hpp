@@ -99,16 +99,17 @@ struct GemmBF3Wide {
     };
 
     // sum over the stage's 32 k of (Ah + Al)[row]: the loader's lane reads its row's four chunks of both parts (any order:
-    // a sum) -- conflict-free, 16 consecutive rows of one position per lane group
+    // a sum)
     __device__ static __forceinline__ float row_part(const lds_c* st, int row, float s) {
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
         // eight independent chains, dependent instructions eight apart (v_dot2c_f32_bf16 accumulates in place)
         u32x4 h[4], l[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            h[c] = *(const lds_u4*)(st + row * 64 + 16 * c);
-            l[c] = *(const lds_u4*)(st + PA + row * 64 + 16 * c);
+        for (int c = 0; c < 4; ++c) {  // the lane walks its row's four chunks from a rotated start: 16 lanes of a ds_read_b128
+            const int pos = ((c + (row >> 2)) & 3) << 4;  // group then hit 16 different 16-byte bank slots (plain order: 4-way conflicts)
+            h[c] = *(const lds_u4*)(st + row * 64 + pos);
+            l[c] = *(const lds_u4*)(st + PA + row * 64 + pos);
         }
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
