@@ -96,8 +96,9 @@ def build_engine(rank, world, use_graph, **engine_kw):
         for q, v in zip(gen.parameters(), params):
             q.copy_(torch.as_tensor(v))
     dev = torch.device("cuda", torch.cuda.current_device())
+    noise = engine_kw.pop("noise", "device")  # (tools/loss_curve.py feeds host-drawn noise to compare with the CPU port)
     eng = NoKLStepEngine(HipOps(), gen.to(dev), torch.as_tensor(data).to(dev), N_BATCH, EPOCH_BATCHES, lr=0.007,
-                         weight_decay=0.04, penalty_weight=10.0, seed=777, noise="device", rank=rank, world=world,
+                         weight_decay=0.04, penalty_weight=10.0, seed=777, noise=noise, rank=rank, world=world,
                          use_graph=use_graph, **engine_kw)
     return eng, data, params
 

@@ -27,7 +27,7 @@ extern "C" {
 #define VGAN_ERR_ARG 1  /* bad shape / null pointer / unsupported configuration */
 #define VGAN_ERR_HIP 2  /* a HIP runtime call or launch failed */
 
-#define VGAN_ABI_VERSION 4
+#define VGAN_ABI_VERSION 5
 
 typedef void* vgan_stream_t; /* hipStream_t */
 
@@ -449,6 +449,15 @@ typedef struct vgan_dp_comm vgan_dp_comm;
 int vgan_dp_unique_id(uint8_t* id /* [VGAN_DP_ID_BYTES] */);
 int vgan_dp_comm_create(vgan_dp_comm** comm, int nranks, const uint8_t* id, int rank);
 int vgan_dp_allreduce_sum(vgan_dp_comm* comm, float* buf, int64_t count, vgan_stream_t stream);
+/* In-place all-gather of raw bytes: rank r's bytes_per_rank bytes already sit at buf + r * bytes_per_rank; afterwards every rank
+ * holds all nranks pieces.  The exchange of the SHARDED front of a data-parallel step (chosen for large
+ * batches, v-gan_amd/trainer.py): each rank runs vgan_linear_forward, vgan_mask_project_forward(row_offset = its first row),
+ * vgan_mmd_bf3_prepare and vgan_colmax_partial for ITS rows only, then the ranks gather the Y rows of the split images (or of
+ * Z in fp32 mode), their norms and the column-key chunks -- three or four calls, or one over a packed record -- while the
+ * Gram tiles that need no other rank's rows (XY, X-X) run on another stream.
+ * STATUS of the four vgan_dp_* calls: exercised on MI355X with nranks = 1 only (a one-GPU box cannot form a larger
+ * communicator); the Python engine carries the same exchanges through torch.distributed (backend "nccl" = RCCL). */
+int vgan_dp_allgather(vgan_dp_comm* comm, void* buf, int64_t bytes_per_rank, vgan_stream_t stream);
 int vgan_dp_comm_destroy(vgan_dp_comm* comm);
 
 /* ---------------------------------------------------------------------------------------------

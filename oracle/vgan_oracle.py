@@ -137,12 +137,14 @@ def mmd_forward(X, Y, U, weight, bw=None):
     return dict(loss=mmd2 + penalty, mmd2=mmd2, penalty=penalty, bw=bw, xx=xx, xy=xy, yy=yy)
 
 
-def mmd_backward(X, Y, U, weight, bw):
+def mmd_backward(X, Y, U, weight, bw, with_dx=False):
     """Closed-form gradient of MMDLossConstrained w.r.t. Y and (the explicit) U argument
     (verified against the reference's autograd by the golden tests).
     Returns (dY, dU_penalty): dU_penalty is only the penalty term's gradient; the caller adds
-    dY * X for the path through Y = U * X (src/vgan.py:616)."""
-    n, d = U.shape
+    dY * X for the path through Y = U * X (src/vgan.py:616).  X and Y may have different row counts (the block means of
+    Mmd_loss_constrained.py:46-49 are over n_x^2, n_x n_y and n_y^2 entries); with_dx: returns (dX, dY, dU_penalty)."""
+    n, m = X.shape[0], Y.shape[0]
+    d = U.shape[1]
     dt = X.dtype
     Z = np.vstack([X, Y])
     s = (Z * Z).sum(axis=1)
@@ -152,8 +154,8 @@ def mmd_backward(X, Y, U, weight, bw):
         dK -= np.exp(-L / sc) / sc
     c = np.zeros_like(L)
     c[:n, :n] = 1.0 / (n * n)
-    c[n:, n:] = 1.0 / (n * n)
-    c[:n, n:] = -2.0 / (n * n)
+    c[n:, n:] = 1.0 / (m * m)
+    c[:n, n:] = -2.0 / (n * m)
     G = c * dK
     Gs = G + G.T
     dZ = 2 * (Gs.sum(axis=1, keepdims=True) * Z - Gs @ Z)
@@ -161,6 +163,8 @@ def mmd_backward(X, Y, U, weight, bw):
     dU = np.zeros_like(U)
     arg = U.argmax(axis=0)  # first maximal row, like a stable top-1
     dU[arg, np.arange(d)] = -weight / d
+    if with_dx:
+        return dZ[:n].astype(dt), dY.astype(dt), dU.astype(dt)
     return dY.astype(dt), dU.astype(dt)
 
 

@@ -21,6 +21,9 @@ alone, so they stay valid across torch versions.
                    per-step loss, final params, generate_subspaces(500) masks
   f4_kl_c1.npz     VGAN.fit (kernel learning) 12 epochs at c1: both loss histories + masks
   f5_c3_scalars.npz  c3 (d=784, n=1024) single step, fp64 + fp32 scalars on documented inputs
+  f7_mmd_unequal.npz  MMDLossConstrained with DIFFERENT row counts of X and Y (Mmd_loss_constrained.py:46-49 takes block means
+                   over whatever shapes it is given; no call site of the reference does this): loss, bandwidth, dX, dY, dU, and
+                   a second call on the frozen bandwidth
   f6_ref_generator_c1.pt, f6_ref_run.npz   a run folder written by the reference's fit(path_to_directory=...): its saved
                    generator state_dict, the masks the reference samples from it after load_models, its CSV texts
 """
@@ -330,7 +333,33 @@ def make_f6():
     print("f6", out["files"], out["model_files"], str(out["params_csv"])[:200], masks.sum(0))
 
 
+# ---------------------------------------------------------------------------- F7
+def make_f7():
+    out = {}
+    for k, (nx, ny, nu, d) in enumerate([(48, 80, 80, 12), (200, 72, 50, 30)]):
+        rng = np.random.default_rng(700 + k)
+        X32 = (rng.normal(size=(nx, d)) + rng.choice([-1.5, 1.5], size=(nx, 1))).astype(np.float32)
+        Y32 = (rng.normal(size=(ny, d)) * 0.8).astype(np.float32)
+        U32 = rng.uniform(0.0, 1.0, size=(nu, d)).astype(np.float32)
+        out.update({f"X{k}": X32, f"Y{k}": Y32, f"U{k}": U32})
+        for dt, tag in [(torch.float32, "f32"), (torch.float64, "f64")]:
+            X = torch.tensor(X32, dtype=dt, requires_grad=True)
+            Y = torch.tensor(Y32, dtype=dt, requires_grad=True)
+            U = torch.tensor(U32, dtype=dt, requires_grad=True)
+            loss_fn = MMDLossConstrained(weight=3.0, kernel=RBF())
+            loss = loss_fn(X, Y, U)  # first call: calibrates the bandwidth on the stacked [X; Y]
+            dX, dY, dU = torch.autograd.grad(loss, [X, Y, U])
+            Y2 = (Y.detach() * 1.1 + 0.05).requires_grad_(True)
+            loss2 = loss_fn(X, Y2, U)  # frozen bandwidth
+            (dY2,) = torch.autograd.grad(loss2, [Y2])
+            for name, v in (("loss", loss), ("bw", loss_fn.bandwidth), ("dX", dX), ("dY", dY), ("dU", dU), ("loss2", loss2), ("dY2", dY2)):
+                out[f"{name}{k}_{tag}"] = t2n(v)
+        print("f7", k, out[f"loss{k}_f32"], out[f"loss{k}_f64"], out[f"bw{k}_f32"])
+    out["weight"] = np.float64(3.0)
+    np.savez_compressed(os.path.join(HERE, "f7_mmd_unequal.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7"]
     for w in which:
         globals()[f"make_{w}"]()

@@ -110,4 +110,11 @@ def test_rccl_wrappers_of_the_c_abi_single_rank():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert torch.equal(t, want)
+    # the sharded front's exchange: in-place all-gather of raw bytes (int16 split images, float norms, int64 keys)
+    for tt in (torch.arange(4096, dtype=torch.int16, device="cuda").view(64, 64), torch.rand(1000, device="cuda"),
+               torch.arange(77, dtype=torch.int64, device="cuda")):
+        keep = tt.clone()
+        ops.dp_allgather(comm, tt, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(tt, keep)
     ops.dp_comm_destroy(comm)

@@ -292,12 +292,15 @@ def make_engine(ops, params, data, n, nb=1, graph=False, noise="host", **kw):
 
 
 @pytest.mark.parametrize("mode", ["collapsed", "layered"])
-@pytest.mark.parametrize("cfg", ["c1", "c2"])
-def test_full_step_golden(ops, cfg, mode):
+@pytest.mark.parametrize("cfg,precision", [("c1", "fp32"), ("c2", "fp32"), ("c2", "bf16x3")])
+def test_full_step_golden(ops, cfg, mode, precision):
+    """Two full steps against the reference's own numbers (fixture F2).  BASELINE.json configs[1] (c2: musk, d=166, batch=512)
+    is specified as bf16: it runs in both arithmetic modes (`auto` would pick the fp32 MFMA at that size)."""
     g = load_golden(f"f2_step_{cfg}.npz")
     batch, noise = g["batch"], g["noise"]
     n = batch.shape[0]
-    eng, gen = make_engine(ops, [g[f"param0_{i}"] for i in range(8)], batch, n, generator_mode=mode)
+    eng, gen = make_engine(ops, [g[f"param0_{i}"] for i in range(8)], batch, n, generator_mode=mode, mmd_precision=precision)
+    assert eng.precision == precision
     eng.set_epoch_batches(torch.arange(n).view(1, n))
     for step in range(2):
         eng.set_noise(torch.as_tensor(noise))
@@ -462,9 +465,36 @@ def test_rbf_module_forward_matrix_and_general_kernels(ops, nk, mf):
     for got, ref in ((Xt.grad, Xr.grad), (Yt.grad, Yr.grad)):
         np.testing.assert_allclose(host(got), ref.numpy(), rtol=0, atol=1e-3 * float(ref.abs().max()))
     with pytest.raises(ValueError):
-        loss_fn(dev(X), dev(Y[:10]), dev(U))
+        loss_fn(dev(X), dev(Y[:, :3]), dev(U))  # different column counts
     with pytest.raises(ValueError):
         RBF(n_kernels=9)
+
+
+def test_mmd_loss_with_unequal_row_counts_golden():
+    """MMDLossConstrained on X [n_x, p], Y [n_y, p] with n_x != n_y and a U of its own row count (the reference's block means
+    over n_x^2, n_x n_y, n_y^2 entries, Mmd_loss_constrained.py:46-49) against fixture F7, written by the reference itself:
+    loss within the 1e-4 bar of its float64 value (and 2e-5 of its float32 one), calibrated bandwidth, dX, dY, dU, and a
+    second call on the frozen bandwidth."""
+    from vgan_amd.modules import MMDLossConstrained, RBF
+    g = load_golden("f7_mmd_unequal.npz")
+    w = float(g["weight"])
+    for k in (0, 1):
+        X, Y, U = (dev(g[f"{a}{k}"]).requires_grad_(True) for a in "XYU")
+        loss_fn = MMDLossConstrained(weight=w, kernel=RBF())
+        loss = loss_fn(X, Y, U)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g[f"loss{k}_f64"])) < 1e-4
+        assert abs(float(loss.detach()) - float(g[f"loss{k}_f32"])) < 2e-5
+        np.testing.assert_allclose(float(loss_fn.bandwidth), float(g[f"bw{k}_f64"]), rtol=1e-5)
+        for t, name in ((X, "dX"), (Y, "dY"), (U, "dU")):
+            ref = g[f"{name}{k}_f64"]
+            np.testing.assert_allclose(host(t.grad), ref, rtol=0, atol=1e-3 * np.abs(ref).max(), err_msg=name)
+        Y2 = dev(g[f"Y{k}"] * np.float32(1.1) + np.float32(0.05)).requires_grad_(True)
+        loss2 = loss_fn(X.detach(), Y2, U.detach())   # frozen bandwidth; gradient to Y only
+        loss2.backward()
+        assert abs(float(loss2.detach()) - float(g[f"loss2{k}_f64"])) < 1e-4
+        ref = g[f"dY2{k}_f64"]
+        np.testing.assert_allclose(host(Y2.grad), ref, rtol=0, atol=1e-3 * np.abs(ref).max())
 
 
 def test_fit_drop_in_matches_reference_run():
@@ -1347,9 +1377,11 @@ def test_kl_step_engine_hip_vs_cpu_provider(ops, n, d):
 def test_kl_step_engine_c3_size_vs_port(ops):
     """VGAN.fit's step engine at the metric's size (d=784, batch=1024, L=49) against oracle/torch_port.PortKL -- the op-for-op
     autograd port of the reference's two step bodies, pinned to the reference's own run by fixture f4
-    (tests/test_oracle_golden.py) -- on identical parameters, batches and noise: two detector steps with the encoder still
-    trainable, one generator-phase step (which freezes the detector), one detector step with the encoder frozen.  Every step's
-    MMD term and squared-error terms, the bandwidth, and all sixteen detector tensors at the end."""
+    (tests/test_oracle_golden.py) -- on identical parameters, batches and noise, over 22 steps in the order a fit runs them
+    (src/vgan.py:251-332): a detector epoch of four steps with the encoder still trainable, five generator-phase epochs of two
+    steps (the first one freezes the detector), a SECOND detector epoch of four steps with the encoder frozen, four more
+    generator-phase steps.  Every step's MMD term and squared-error terms, the bandwidth, and all sixteen detector tensors at
+    the end."""
     from oracle import torch_port as port
     from vgan_amd.kl_trainer import KLStepEngine
     from vgan_amd.modules import Decoder, Detector, Encoder, Generator_big
@@ -1368,7 +1400,8 @@ def test_kl_step_engine_c3_size_vs_port(ops):
     tr = port.PortKL(gen_params, det_params, lr_D=0.007, weight_decay=0.04, weight=10.0)
     eng = KLStepEngine(ops, gen.cuda(), det.cuda(), dev(data), n, 0.007, 0.04, 10.0)
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-    for kind, enc_train in (("d", True), ("d", True), ("g", False), ("d", False)):
+    schedule = [("d", True)] * 4 + [("g", False)] * 10 + [("d", False)] * 4 + [("g", False)] * 4
+    for kind, enc_train in schedule:
         idx = rng.permutation(4 * n)[:n]
         z = rng.normal(size=(n, L)).astype(np.float32)
         X, zt = torch.as_tensor(data[idx]), torch.as_tensor(z)

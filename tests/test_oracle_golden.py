@@ -170,3 +170,24 @@ def test_f4_port_kl_reproduces_reference_vgan_fit():
     for i, q in enumerate(tr.det):
         np.testing.assert_allclose(q.detach().numpy(), g[f"detT_{i}"], rtol=0, atol=1e-6)
         assert bool(q.requires_grad) == bool(g[f"detT_rg_{i}"])
+
+
+def test_oracle_mmd_with_unequal_row_counts_vs_reference():
+    """Fixture F7: the reference's MMDLossConstrained on X and Y of DIFFERENT row counts (Mmd_loss_constrained.py:46-49: block
+    means over n_x^2, n_x n_y, n_y^2 entries; U with its own row count) -- loss, calibrated bandwidth, dX, dY, dU and a second
+    call on the frozen bandwidth, float64 and float32."""
+    g = load_golden("f7_mmd_unequal.npz")
+    w = float(g["weight"])
+    for k in (0, 1):
+        for tag, dt, tol in (("f64", np.float64, 1e-10), ("f32", np.float32, 2e-5)):
+            X, Y, U = g[f"X{k}"].astype(dt), g[f"Y{k}"].astype(dt), g[f"U{k}"].astype(dt)
+            f = orc.mmd_forward(X, Y, U, w)
+            assert abs(f["loss"] - float(g[f"loss{k}_{tag}"])) < tol * max(1.0, abs(float(g[f"loss{k}_{tag}"])))
+            np.testing.assert_allclose(float(f["bw"]), float(g[f"bw{k}_{tag}"]), rtol=10 * tol)
+            dX, dY, dU = orc.mmd_backward(X, Y, U, w, f["bw"], with_dx=True)
+            for got, name in ((dX, "dX"), (dY, "dY"), (dU, "dU")):
+                ref = g[f"{name}{k}_{tag}"]
+                np.testing.assert_allclose(got, ref, rtol=0, atol=(1e-9 if dt is np.float64 else 2e-5) * max(np.abs(ref).max(), 1e-12) + 1e-12)
+            Y2 = (Y * dt(1.1) + dt(0.05)).astype(dt)
+            f2 = orc.mmd_forward(X, Y2, U, w, bw=f["bw"])
+            assert abs(f2["loss"] - float(g[f"loss2{k}_{tag}"])) < tol * max(1.0, abs(float(g[f"loss2{k}_{tag}"])))

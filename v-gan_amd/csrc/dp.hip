@@ -3,6 +3,9 @@
 // with the collapsed chain) on the caller's stream, between the weight-gradient contraction and the optimiser -- the point
 // of the reference's `backward(); step()` (src/vgan.py:618-619).  The reference itself has no collective.
 //
+// With the SHARDED front of the step (large batches: v-gan_amd/trainer.py) there is a second exchange before the Gram: the
+// all-gather of the Y rows of the operand, their norms and the column keys (vgan_dp_allgather, in place, byte counts).
+//
 // RCCL is opened lazily (dlopen of librccl.so) so that the library loads -- and every other entry point works -- on hosts
 // without it; one process per GPU, communicators created from an id that rank 0 obtains and the caller distributes.
 #include <dlfcn.h>
@@ -105,6 +108,16 @@ extern "C" int vgan_dp_allreduce_sum(vgan_dp_comm* comm, float* buf, int64_t cou
     VGAN_NEED_RCCL();
     const ncclResult_t rc = rccl().all_reduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, comm->comm, (hipStream_t)stream);
     if (rc != ncclSuccess) return fail("ncclAllReduce", rc);
+    return VGAN_OK;
+}
+
+extern "C" int vgan_dp_allgather(vgan_dp_comm* comm, void* buf, int64_t bytes_per_rank, vgan_stream_t stream) {
+    VGAN_CHECK_ARG(comm && buf && bytes_per_rank > 0);
+    VGAN_NEED_RCCL();
+    // in place: rank r's contribution already sits at buf + r * bytes_per_rank (RCCL's in-place all-gather convention)
+    const char* mine = static_cast<const char*>(buf) + (int64_t)comm->rank * bytes_per_rank;
+    const ncclResult_t rc = rccl().all_gather(mine, buf, (size_t)bytes_per_rank, ncclChar, comm->comm, (hipStream_t)stream);
+    if (rc != ncclSuccess) return fail("ncclAllGather", rc);
     return VGAN_OK;
 }
 

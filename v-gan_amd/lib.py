@@ -109,11 +109,12 @@ SIGNATURES = {
     "vgan_dp_unique_id": (_i, [_p]),
     "vgan_dp_comm_create": (_i, [_p, _i, _p, _i]),
     "vgan_dp_allreduce_sum": (_i, [_p, _p, _i64, _p]),
+    "vgan_dp_allgather": (_i, [_p, _p, _i64, _p]),
     "vgan_dp_comm_destroy": (_i, [_p]),
     "vgan_mse": (_i, [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -324,6 +324,75 @@ class _MMDLossFn(torch.autograd.Function):
         return dX, dY, dU, None, None
 
 
+class _MMDLossUnequalFn(torch.autograd.Function):
+    """MMDLossConstrained for X [n_x, p] and Y [n_y, p] with n_x != n_y (and U with any row count), as
+    src/models/Mmd_loss_constrained.py:42-50 computes it: block means of K([X; Y]) over n_x^2, n_x n_y and n_y^2 entries.  The
+    training step never takes this path (its Y is a function of U * X: equal shapes, fused tile tables); here the N x N kernel
+    matrix is materialised by vgan_rbf_multi_kernel_matrix, the block sums are float64 row dots against a row of ones
+    (vgan_rows_dot / vgan_sum_f64), and the gradient is the MMD backward product on W = (gK + gK^T) * dK/dL with gK the
+    block-constant upstream gradient of the three means."""
+
+    @staticmethod
+    def forward(ctx, X, Y, U, weight, kernel):
+        ops = default_ops()
+        dev = X.device
+        nx, p = X.shape
+        ny, d = Y.shape[0], U.shape[1]
+        N, pp = nx + ny, _round4(p)
+        Z = torch.zeros(N, pp, dtype=torch.float32, device=dev)
+        Z[:nx, :p].copy_(X)
+        Z[nx:, :p].copy_(Y)
+        sq = torch.empty(N, dtype=torch.float32, device=dev)
+        ops.row_sqnorm(Z, sq, pp)
+        bw = kernel._device_bandwidth(Z, sq, N, pp)  # first call: sum of all squared distances of the stacked rows / (N^2 - N)
+        Np = _round4(N)
+        K = torch.zeros(N, Np, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dK = torch.zeros(N, Np, dtype=torch.float32, device=dev) if need else None
+        ops.rbf_multi_kernel_matrix(Z, sq, bw, kernel.bandwidth_multipliers.tolist(), K, dK)
+        ones = torch.ones(1, Np, dtype=torch.float32, device=dev)
+        rows = torch.empty(N, dtype=torch.float64, device=dev)
+        sums = torch.zeros(3, dtype=torch.float32, device=dev)
+        stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        for slot, (r0, r1, c0, c1) in enumerate(((0, nx, 0, nx), (0, nx, nx, N), (nx, N, nx, N))):  # XX, XY, YY
+            ops.rows_dot(K[r0:r1, c0:c1], ones[:, :c1 - c0], rows, broadcast_b=True)
+            ops.sum_f64(rows, r1 - r0, 1.0 / (float(r1 - r0) * float(c1 - c0)), sums[slot:slot + 1])
+        stats[:3].copy_(sums)  # the three block MEANS; vgan_mmd_loss then forms xx - 2 xy + yy (its n = 1) + the penalty
+        Uc = U.detach().contiguous().float()
+        colpart = torch.empty(ops.colmax_chunks(Uc.shape[0]) * d, dtype=torch.int64, device=dev)
+        colkey = torch.empty(d, dtype=torch.int64, device=dev)
+        ops.colmax(Uc, 0, colpart, colkey, False)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.mmd_loss(stats, colkey, 1, d, float(weight), loss)
+        ctx.save_for_backward(Z, colkey, dK) if need else ctx.save_for_backward(Z, colkey)
+        ctx.dims, ctx.weight, ctx.nu = (nx, ny, p, pp, d), float(weight), Uc.shape[0]
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        ops = default_ops()
+        Z, colkey = ctx.saved_tensors[:2]
+        nx, ny, p, pp, d = ctx.dims
+        N = nx + ny
+        dX = dY = dU = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            W = ctx.saved_tensors[2]  # dK/dL, scaled in place by (gK + gK^T): 2 / n_x^2 | -2 / (n_x n_y) | 2 / n_y^2 per block
+            W[:nx, :nx].mul_(2.0 / (float(nx) * nx))
+            W[:nx, nx:N].mul_(-2.0 / (float(nx) * ny))
+            W[nx:, :nx].mul_(-2.0 / (float(nx) * ny))
+            W[nx:, nx:N].mul_(2.0 / (float(ny) * ny))
+            out = torch.empty(N, pp, dtype=torch.float32, device=Z.device)
+            ops.mmd_backward(W, Z, 0, N, N, pp, None, out)
+            out = out[:, :p] * gl
+            dX, dY = out[:nx], out[nx:]
+        if ctx.needs_input_grad[2]:
+            rows = 0xFFFFFFFF - (colkey & 0xFFFFFFFF)
+            dU = torch.zeros(ctx.nu, d, dtype=torch.float32, device=Z.device)
+            dU[rows, torch.arange(d, device=Z.device)] = -ctx.weight / d
+            dU = dU * gl
+        return dX, dY, dU, None, None
+
+
 class MMDLossConstrained(nn.Module):
     """src/models/Mmd_loss_constrained.py:29-50.  As in the reference, the default ``kernel=RBF()`` is
     evaluated once at class-definition time: every instance created without an explicit kernel
@@ -335,14 +404,16 @@ class MMDLossConstrained(nn.Module):
         self.weight = weight
 
     def forward(self, X, Y, U):
-        # the reference takes block means over arbitrary row counts of X and Y (Mmd_loss_constrained.py:46-49); every caller in
-        # the reference passes Y = f(U * X), i.e. equal shapes, and the tile tables of this build assume that
-        if X.dim() != 2 or Y.shape != X.shape:
-            raise ValueError(f"MMDLossConstrained: X and Y must be 2-D with equal shapes on this build, got {tuple(X.shape)} and "
+        if X.dim() != 2 or Y.dim() != 2 or X.shape[1] != Y.shape[1]:
+            raise ValueError(f"MMDLossConstrained: X and Y must be 2-D with the same number of columns, got {tuple(X.shape)} and "
                              f"{tuple(Y.shape)}")
-        if U.dim() != 2 or U.shape[0] != X.shape[0]:
-            raise ValueError(f"MMDLossConstrained: U must be [n, d] with n = {X.shape[0]} rows, got {tuple(U.shape)}")
-        out = _MMDLossFn.apply(X.contiguous().float(), Y.contiguous().float(), U, self.weight, self.kernel)
+        if U.dim() != 2:
+            raise ValueError(f"MMDLossConstrained: U must be 2-D [rows, d], got {tuple(U.shape)}")
+        # the reference takes block means over arbitrary row counts of X and Y (Mmd_loss_constrained.py:46-49); every caller in
+        # the reference passes Y = f(U * X), i.e. equal shapes: that is the fused tile path.  Anything else (n_x != n_y, or a U
+        # with another row count) takes the general path on the materialised kernel matrix.
+        fn = _MMDLossFn if (Y.shape == X.shape and U.shape[0] == X.shape[0]) else _MMDLossUnequalFn
+        out = fn.apply(X.contiguous().float(), Y.contiguous().float(), U, self.weight, self.kernel)
         self.bandwidth = self.kernel.bandwidth
         self.bandwidth_multipliers = self.kernel.bandwidth_multipliers
         return out

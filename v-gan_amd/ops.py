@@ -479,6 +479,11 @@ class HipOps:
         _vec(t, "t")
         _lib.check(self.lib.vgan_dp_allreduce_sum(comm, _ptr(t), t.numel(), self._stream()), "vgan_dp_allreduce_sum")
 
+    def dp_allgather(self, comm, t, nranks):
+        """In-place all-gather over dim 0 of a contiguous tensor: rank r's slice is t[r * len(t) // nranks ...]."""
+        assert t.is_cuda and t.is_contiguous() and t.shape[0] % nranks == 0
+        _lib.check(self.lib.vgan_dp_allgather(comm, _ptr(t), t.numel() * t.element_size() // nranks, self._stream()), "vgan_dp_allgather")
+
     def dp_comm_destroy(self, comm):
         _lib.check(self.lib.vgan_dp_comm_destroy(comm), "vgan_dp_comm_destroy")
 
