@@ -112,6 +112,7 @@ class NoKLStepEngine:
         self.steps_per_graph = max(1, min(16, int(batches_per_epoch)))
         self.steps_done = 0
         self._xx_primed = False  # overlap mode: have the X-X sums of the upcoming batch been computed?
+        self._coalesce = None    # sharded front: may the gathers share one collective launch?  (probed at first use)
         self.mode = generator_mode or os.environ.get("VGAN_GENERATOR", "collapsed")
         if self.mode not in ("collapsed", "layered"):
             raise ValueError(f"generator_mode must be 'collapsed' or 'layered', got {self.mode!r}")
@@ -411,6 +412,8 @@ class NoKLStepEngine:
         own = ops.colmax_chunks(nl) * d
         self.colpart_own = self.colpart[rank * own:(rank + 1) * own] if self.front_sharded else self.colpart
         self.colkey = torch.zeros(d, dtype=torch.int64, device=self.dev)
+        if self.front_sharded and data.is_cuda and self._collect().is_initialized():
+            self._coalesce = self._probe_coalescing(self._collect())  # here, eagerly: the first exchange may run inside a capture
 
     # ---- host-side controls ---------------------------------------------------------------------
     def set_epoch_batches(self, idx):
@@ -736,15 +739,44 @@ class NoKLStepEngine:
         Returns the pending work handles; the caller runs the tiles that need none of it meanwhile."""
         n, nl, lo = self.n, self.nl, self.lo
         yown = slice(n + lo, n + lo + nl)
-        works = []
+        pairs = []
         if self.bf3:  # (int16 images travel as int32 words: gloo has no 16-bit integer type)
-            for img in (self.Zh, self.Zl):
-                works.append(self._all_gather(dist, img[n:2 * n].view(torch.int32), img[yown].view(torch.int32)))
+            pairs += [(img[n:2 * n].view(torch.int32), img[yown].view(torch.int32)) for img in (self.Zh, self.Zl)]
         else:
-            works.append(self._all_gather(dist, self.Z[n:], self.Z[yown]))
-        works.append(self._all_gather(dist, self.sqn[n:], self.sqn[yown]))
-        works.append(self._all_gather(dist, self.colpart, self.colpart_own))
-        return works
+            pairs.append((self.Z[n:], self.Z[yown]))
+        pairs += [(self.sqn[n:], self.sqn[yown]), (self.colpart, self.colpart_own)]
+        if self._coalesce is None:
+            self._coalesce = self._probe_coalescing(dist)
+        if self._coalesce:  # one RCCL group launch for the three or four gathers instead of one launch each
+            emulated = dist.get_world_size(self.group) != self.world
+            with dist._coalescing_manager(group=self.group, device=self.dev, async_ops=True) as cm:
+                for out, own in pairs:
+                    dist.all_gather_into_tensor(own if emulated else out, own, group=self.group)
+            return [cm]
+        return [self._all_gather(dist, out, own) for out, own in pairs]
+
+    def _probe_coalescing(self, dist):
+        """Can this stack batch several all-gathers into one collective launch (torch's coalescing manager over RCCL's group
+        calls)?  Tried ONCE, eagerly, on scratch tensors -- never for the first time inside a graph capture -- and only on the
+        RCCL backend; any failure means "one launch per gather", never "no exchange"."""
+        if os.environ.get("VGAN_DP_COALESCE", "1") != "1" or not self.data.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        try:
+            if dist.get_backend(self.group) != "nccl" or not hasattr(dist, "_coalescing_manager"):
+                return False
+            size = dist.get_world_size(self.group)
+            a, b = torch.zeros(size * 4, device=self.dev), torch.zeros(size * 2, dtype=torch.int64, device=self.dev)
+            r = dist.get_rank(self.group)
+            with dist._coalescing_manager(group=self.group, device=self.dev, async_ops=True) as cm:
+                dist.all_gather_into_tensor(a, a[4 * r:4 * r + 4], group=self.group)
+                dist.all_gather_into_tensor(b, b[2 * r:2 * r + 2], group=self.group)
+            cm.wait()
+            torch.cuda.synchronize()
+            return True
+        except Exception as e:  # noqa: BLE001
+            import warnings
+            warnings.warn(f"vgan_amd: coalesced all-gather is not available on this stack ({type(e).__name__}: {e}); one launch per gather")
+            return False
 
     def _loss_backward_update_sharded(self, all_rows_here=False):
         """Gram (own Y rows x all columns + a share of the X-X triangle), backward, mask backward, M_4, all-reduce, chain
