@@ -304,11 +304,19 @@ int vgan_mmd_backward_bf3_rm_xx(const uint16_t* Wh, const uint16_t* Wl, int ldw,
 #define VGAN_GEMM_NN 0
 #define VGAN_GEMM_NT 1
 #define VGAN_GEMM_TN 2
+#define VGAN_GEMM_NT_NT 3 /* two products in one tile: C[m,n] = (A[m,k] . B[k2,k]^T) . D[n,k2]^T -- a 64 x 64 tile of C first forms its 64
+                           * rows of H = A . B^T ([64, k2], into `scratch`: ceil(m/64) * ceil(n/64) regions of 64 * round4(k2)
+                           * floats, one per tile) and then multiplies them with D.  For a dependent pair of small products whose
+                           * second would otherwise cost a launch of its own (the logits of the collapsed generator: T = ([z|1] .
+                           * Wt_1^T) . Wt_2^T rides with the first level of chain products, src/models/Generator.py:61-66). */
 typedef struct vgan_gemm_problem {
     const float* a;
     const float* b;
     float* c;
     int32_t kind, m, n, k, lda, ldb, ldc, splitk;
+    const float* d;   /* VGAN_GEMM_NT_NT only */
+    float* scratch;   /* VGAN_GEMM_NT_NT only */
+    int32_t ldd, k2;  /* VGAN_GEMM_NT_NT only: D [n, k2] row-major */
 } vgan_gemm_problem;
 int vgan_gemm_grouped(const vgan_gemm_problem* problems, int count, vgan_stream_t stream);
 /* The same launch with work riding in it (each part optional; a dependent launch costs ~5 us whatever its size, so the

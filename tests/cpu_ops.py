@@ -424,9 +424,12 @@ class CpuOps:
 
     def gemm_grouped(self, problems, copy=None, adadelta=None, noise=None, fold=None):
         outs = []
-        problems = [tuple(q[:4]) if len(q) == 4 or q[4] <= 1 else (q[0], q[1], q[2], q[3], q[4]) for q in problems]
-        for kind, A, B, *_ in problems:  # all reads before any write: the products are independent by contract
+        problems = [q if q[0] == "NT2" else (tuple(q[:4]) if len(q) == 4 or q[4] <= 1 else (q[0], q[1], q[2], q[3], q[4])) for q in problems]
+        for kind, A, B, *rest in problems:  # all reads before any write: the products are independent by contract
             a, b = _np(A).astype(np.float64), _np(B).astype(np.float64)
+            if kind == "NT2":  # (A . B^T) . D^T, the intermediate rounded to float32 like the kernel's scratch
+                outs.append((a @ b.T).astype(np.float32).astype(np.float64) @ _np(rest[1]).astype(np.float64).T)
+                continue
             outs.append(a @ b if kind == "NN" else a @ b.T if kind == "NT" else a.T @ b)
         if noise is not None:  # reads the step counter as the launch finds it
             self.noise_normal(noise["next_noise"], noise["seed"], noise["step_counter"], 0, cols=noise["noise_cols"],
@@ -435,7 +438,7 @@ class CpuOps:
             copy[1].copy_(copy[0])
         for q, r in zip(problems, outs):
             C = q[3]
-            if len(q) > 4:  # split-K slabs: the CPU stand-in puts the whole product in slab 0
+            if q[0] != "NT2" and len(q) > 4:  # split-K slabs: the CPU stand-in puts the whole product in slab 0
                 C.zero_()
                 C = C[0]
             C.copy_(torch.as_tensor(r))

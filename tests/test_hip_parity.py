@@ -1187,6 +1187,47 @@ def test_gemm_grouped_vs_numpy(ops, case):
     assert float(C[:, 40:].abs().max()) == 0.0
 
 
+def test_two_stage_logits_schedule_vs_golden(ops, monkeypatch):
+    """The opt-in two-launch generator forward (VGAN_LOGITS_2STAGE=1: logits = (([z|1] . Wt_1^T) . Wt_2^T) . B_3^T with the first
+    two products as one two-stage tile) against fixture F2 (c2), like the default schedule."""
+    monkeypatch.setenv("VGAN_LOGITS_2STAGE", "1")
+    g = load_golden("f2_step_c2.npz")
+    batch, noise = g["batch"], g["noise"]
+    n = batch.shape[0]
+    eng, gen = make_engine(ops, [g[f"param0_{i}"] for i in range(8)], batch, n)
+    assert eng.two_stage_logits
+    eng.set_epoch_batches(torch.arange(n).view(1, n))
+    for step in range(2):
+        eng.set_noise(torch.as_tensor(noise))
+        eng.step()
+        assert abs(float(eng.loss) - float(g[f"loss{step}"])) < 2e-5
+        for i in range(8):
+            np.testing.assert_allclose(host(eng.fp.view(eng.fp.flat, i)), g[f"param{step + 1}_{i}"], rtol=0, atol=5e-6)
+
+
+def test_gemm_grouped_two_stage_tile(ops):
+    """vgan_gemm_problem kind NT_NT: C = (A . B^T) . D^T formed tile by tile in ONE launch (the logits' first half riding with the
+    chain products), beside ordinary products, against float64 numpy -- the step's shapes, ragged shapes (rows, both inner
+    dimensions and columns no multiples of the tile), and the same bits twice."""
+    rng = np.random.default_rng(5)
+    T = lambda *shape: torch.as_tensor(rng.normal(size=shape).astype(np.float32)).cuda()
+    for (m, k, k2, n) in [(1024, 52, 100, 200), (130, 20, 36, 72), (64, 8, 132, 64), (200, 260, 516, 100)]:
+        A, B, D = T(m, k), T(k2, k), T(n, k2)
+        other_a, other_b = T(100, 52), T(52, 40)
+        outs = []
+        for rep in range(2):
+            C = torch.full((m, n), float("nan"), device="cuda")
+            O = torch.full((100, 40), float("nan"), device="cuda")
+            ws = torch.full((((m + 63) // 64) * ((n + 63) // 64) * 64 * ((k2 + 3) // 4 * 4),), float("nan"), device="cuda")
+            ops.gemm_grouped([("NN", other_a, other_b, O), ("NT2", A, B, C, D, ws)])
+            outs.append((host(C).copy(), host(O).copy()))
+        a, b, d = (host(x).astype(np.float64) for x in (A, B, D))
+        want = (a @ b.T) @ d.T
+        np.testing.assert_allclose(outs[0][0], want, rtol=0, atol=3e-5 * np.abs(want).max(), err_msg=str((m, k, k2, n)))
+        np.testing.assert_allclose(outs[0][1], host(other_a).astype(np.float64) @ host(other_b).astype(np.float64), rtol=0, atol=1e-4)
+        assert np.array_equal(outs[0][0], outs[1][0])
+
+
 def test_gemm_grouped_split_k_slabs(ops):
     """vgan_gemm_problem.splitk: the contraction cut into slices run by different workgroups, partial products in slabs that
     vgan_reduce_slabs sums (the chain products of c4 / c5: long contraction, few output tiles).  All three kinds in one launch

@@ -169,6 +169,40 @@ __device__ __forceinline__ void tile_ks(const vgan_gemm_problem& q, int t, float
     if constexpr (EPI) upd.finish(x, x.layer[qi], col, o, row_of);
 }
 
+// C tile = (A[m0 .., :k] . B[:k2, :k]^T) . D[n0 .., :k2]^T: the tile's 64 rows of H = A . B^T go through the problem's scratch
+// region (global memory, L2-hot: written and re-read by this workgroup only, behind a __syncthreads, whose fence drains the
+// stores), then the second product reads them as its A operand.
+template <int VEC>
+__device__ __forceinline__ void tile64_two_stage(const vgan_gemm_problem& q, int t, float* lds) {
+    using G = GemmTile<QBM, QBM, QBK, KC, KC, VEC>;
+    const int gx = (q.n + QBM - 1) / QBM;
+    const int m0 = (t / gx) * QBM, n0 = (t % gx) * QBM;
+    const int ldh = (q.k2 + 3) / 4 * 4;
+    float* H = q.scratch + (long)t * QBM * ldh;
+    const int rows = min(QBM, q.m - m0);
+    for (int c0 = 0; c0 < q.k2; c0 += QBM) {
+        f32x16 acc[1][1];
+        zero_acc(acc);
+        G::template run<false>(q.a, q.lda, q.b, q.ldb, m0, c0, q.m, q.k2, q.k, lds, nullptr, acc);
+        const int col = c0 + G::sub_col(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = G::sub_row(0, r);
+            if (row < rows && col < ldh) H[(long)row * ldh + col] = col < q.k2 ? acc[0][0][r] : 0.f;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    G::template run<false>(H, ldh, q.d, q.ldd, 0, n0, rows, q.n, q.k2, lds, nullptr, acc);
+    const int col = n0 + G::sub_col(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + G::sub_row(0, r);
+        if (row < q.m && col < q.n) q.c[(long)row * q.ldc + col] = acc[0][0][r];
+    }
+}
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template <int VEC, bool EPI>
@@ -197,6 +231,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_grouped_kernel(GroupedArgs g, 
         if (g.ks[qi]) tile_ks<KC, MC, VEC, 4, EPI>(q, t, lds, x, qi); else tile64<KC, MC, VEC, EPI>(q, t, lds, x, qi);
     } else if (q.kind == VGAN_GEMM_NT) {  // C = A[m,k] . B[n,k]^T
         if (g.ks[qi]) tile_ks<KC, KC, VEC, 4, EPI>(q, t, lds, x, qi); else tile64<KC, KC, VEC, EPI>(q, t, lds, x, qi);
+    } else if (q.kind == VGAN_GEMM_NT_NT) {  // C = (A[m,k] . B[k2,k]^T) . D[n,k2]^T
+        tile64_two_stage<VEC>(q, t, lds);
     } else {                              // C = A[k,m]^T . B[k,n]
         if (g.ks[qi]) tile_ks<MC, MC, VEC, 4, EPI>(q, t, lds, x, qi); else tile64<MC, MC, VEC, EPI>(q, t, lds, x, qi);
     }
@@ -243,15 +279,21 @@ extern "C" int vgan_gemm_grouped_ex(const vgan_gemm_problem* problems, int count
     for (int i = 0; i < count; ++i) {
         const vgan_gemm_problem& q = problems[i];
         VGAN_CHECK_ARG(q.a && q.b && q.c && q.m > 0 && q.n > 0 && q.k > 0 && q.ldc >= q.n);
-        VGAN_CHECK_ARG(q.kind == VGAN_GEMM_NN || q.kind == VGAN_GEMM_NT || q.kind == VGAN_GEMM_TN);
-        VGAN_CHECK_ARG(q.lda >= (q.kind == VGAN_GEMM_TN ? q.m : q.k) && q.ldb >= (q.kind == VGAN_GEMM_NT ? q.k : q.n));
+        VGAN_CHECK_ARG(q.kind == VGAN_GEMM_NN || q.kind == VGAN_GEMM_NT || q.kind == VGAN_GEMM_TN || q.kind == VGAN_GEMM_NT_NT);
+        const bool two = q.kind == VGAN_GEMM_NT_NT;
+        VGAN_CHECK_ARG(q.lda >= (q.kind == VGAN_GEMM_TN ? q.m : q.k) && q.ldb >= ((q.kind == VGAN_GEMM_NT || two) ? q.k : q.n));
+        if (two) {
+            VGAN_CHECK_ARG(q.d && q.scratch && q.k2 > 0 && q.ldd >= q.k2 && q.splitk <= 1 && aligned16(q.scratch));
+            vec = vec && (q.k2 % 4 == 0) && (q.ldd % 4 == 0) && aligned16(q.d);
+            any_split = true;  // (keeps the launch on the 64 x 64 tile kernel, without the optimiser epilogue)
+        }
         vec = vec && (q.m % 4 == 0) && (q.n % 4 == 0) && (q.k % 4 == 0) && (q.lda % 4 == 0) && (q.ldb % 4 == 0) && aligned16(q.a) &&
               aligned16(q.b);
         const long t64 = (long)((q.m + 63) / 64) * ((q.n + 63) / 64);
         // a long contraction over few tiles: the K loop is the critical path -> 32x32 tiles with K split over the waves, as
         // long as they still fit the chip in one round (2 workgroups per CU)
         const long t32 = (long)((q.m + 31) / 32) * ((q.n + 31) / 32);
-        g.ks[i] = (q.k >= 128 && t32 <= 512) ? 1 : 0;
+        g.ks[i] = (q.k >= 128 && t32 <= 512 && !two) ? 1 : 0;
         g.p[i] = q;
         g.tile_start[i] = tiles;
         // split-K across WORKGROUPS (splitk > 1): a product with a long contraction and too few 64 x 64 tiles to load the chip

@@ -22,7 +22,8 @@ class FinalizeJob(ctypes.Structure):
 class GemmProblem(ctypes.Structure):
     """struct vgan_gemm_problem (include/vgan_hip.h)."""
     _fields_ = [("a", _p), ("b", _p), ("c", _p), ("kind", ctypes.c_int32), ("m", ctypes.c_int32), ("n", ctypes.c_int32),
-                ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("splitk", ctypes.c_int32)]
+                ("k", ctypes.c_int32), ("lda", ctypes.c_int32), ("ldb", ctypes.c_int32), ("ldc", ctypes.c_int32), ("splitk", ctypes.c_int32),
+                ("d", _p), ("scratch", _p), ("ldd", ctypes.c_int32), ("k2", ctypes.c_int32)]
 
 
 class LogitsChain(ctypes.Structure):
@@ -51,7 +52,7 @@ class GroupedExtras(ctypes.Structure):
                 ("noise_ones_col", ctypes.c_int32), ("seed", _u64), ("step_counter", _p), ("fold", _p)]
 
 
-GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
+GEMM_NN, GEMM_NT, GEMM_TN, GEMM_NT_NT = 0, 1, 2, 3
 GEMM_MAX_GROUP = 4
 
 # name -> (restype, argtypes); must list every function declared in include/vgan_hip.h

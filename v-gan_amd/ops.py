@@ -14,6 +14,10 @@ from . import lib as _lib
 _f32 = torch.float32
 
 
+def _round4(v):
+    return (int(v) + 3) // 4 * 4
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -385,6 +389,17 @@ class HipOps:
         assert 1 <= len(problems) <= _lib.GEMM_MAX_GROUP
         arr = (_lib.GemmProblem * len(problems))()
         for q, (kind, A, B, C, *rest) in zip(arr, problems):
+            if kind == "NT2":  # C = (A . B^T) . D^T in one tile pass: (kind, A, B, C, D, scratch)
+                D, scratch = rest
+                _mat(A, "A"), _mat(B, "B"), _mat(C, "C"), _mat(D, "D")
+                (m, k), (k2, kb), (n, k2d) = A.shape, B.shape, D.shape
+                assert k == kb and k2 == k2d and tuple(C.shape) == (m, n)
+                tiles = ((m + 63) // 64) * ((n + 63) // 64)
+                assert scratch.is_cuda and scratch.dtype == _f32 and scratch.is_contiguous() and scratch.numel() >= tiles * 64 * _round4(k2)
+                q.a, q.b, q.c, q.d, q.scratch = A.data_ptr(), B.data_ptr(), C.data_ptr(), D.data_ptr(), scratch.data_ptr()
+                q.kind, q.m, q.n, q.k, q.k2, q.splitk = _lib.GEMM_NT_NT, m, n, k, k2, 1
+                q.lda, q.ldb, q.ldc, q.ldd = A.stride(0), B.stride(0), C.stride(0), D.stride(0)
+                continue
             q.splitk = int(rest[0]) if rest else 1
             if q.splitk > 1:
                 assert C.dim() == 3 and C.shape[0] == q.splitk and C.is_contiguous()

@@ -293,6 +293,18 @@ class NoKLStepEngine:
         self.chain_in_mask = (self.mode == "collapsed" and not self.front_sharded and ops.chain_fusable(n, d, data.stride(0), dp) and
                               (not self.bf3 or self.fused_prepare) and os.environ.get("VGAN_CHAIN_IN_MASK", "0") == "1")
         self._chain = None
+        # collapsed generator, depth-first association, opt-in (VGAN_LOGITS_2STAGE=1): the logits product as the second half of a
+        # two-stage tile (see _generator_forward) -- one dependent launch less per step.  MEASURED (MI355X, c3, same box,
+        # alternating runs): 9 285, 9 265 steps/s against 9 702, 9 715 with the three-launch forward (fp32 mode 6 324-6 337 vs
+        # 6 522-6 544): the two carrying launches grow by more than the 5.1 us launch they replace (a two-stage tile is three
+        # dependent K loops and a workgroup barrier deep; the logits as a K = 200 product over 208 tiles is no longer a 5 us
+        # launch's worth riding in a 6.8 us one).  Off by default.
+        self.two_stage_logits = (self.mode == "collapsed" and not self.chain_flops and not self.chain_in_mask and not self.front_sharded and
+                                 os.environ.get("VGAN_LOGITS_2STAGE", "0") == "1")
+        if self.two_stage_logits:
+            e2 = self.e[2]
+            self.T = torch.zeros(n, e2, **f32)  # [z|1] . At_2^T
+            self.T_ws = torch.zeros(((n + 63) // 64) * ((e2 + 63) // 64) * 64 * _round4(self.e[1]), **f32)
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
         # Gram tile edge: the split-bf16 Gram has a 128x128 variant (half the L2 -> LDS bytes per flop, one 512-thread
         # workgroup per CU).  Measured: c5 330 vs 273 TFLOP/s algorithmic, c3 (136 tiles of 128) no gain (26.3 vs 25.6 us),
@@ -525,6 +537,13 @@ class NoKLStepEngine:
                     ops.reduce_slabs(self.chain_ws, At[k].numel(), sp, At[k])
                 else:
                     ops.gemm_grouped([("NN", Wt[k], At[k - 1], At[k])])
+        elif self.two_stage_logits:
+            # ... and the logits WITHOUT a launch of their own: T = [z|1] . At_2^T = ([z|1] . Wt_1^T) . Wt_2^T rides in the first
+            # level as a two-stage tile (vgan_gemm_problem NT_NT), logits = T . B_3^T in the second beside At_3 and B_2.  At_4 is
+            # then not formed at all (nothing but the logits read it): forward 3 -> 2 dependent launches.
+            ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3), ("NT2", self.za, Wt[1], self.T, Wt[2], self.T_ws)])
+            ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, Wt[2], self.B2), ("NT", self.T, self.B3[:self.d], self.logits)])
+            return
         else:                 # two dependency levels through the suffix products B_3, B_2
             ops.gemm_grouped([("NN", Wt[2], At[1], At[2]), ("NN", Wt[4], Wt[3], self.B3)])
             ops.gemm_grouped([("NN", Wt[3], At[2], At[3]), ("NN", self.B3, At[2], At[4]), ("NN", self.B3, Wt[2], self.B2)])
