@@ -162,7 +162,12 @@ int vgan_upper_softmax_forward(const float* logits, int ldl, float* S, float* U,
  * wrow0 = n), 2 = gradient for all rows (Wg is [2n, 2n], wrow0 = 0).
  * Row-sharded data parallel: rank `rank` of `world` owns rows [rank*n/world, (rank+1)*n/world)
  * of each half; its table covers exactly the pairs (own row, any column), without symmetry.
- * tile: edge of the square tiles, 64 (every kernel) or 128 (vgan_mmd_gram_bf3 only).
+ * tile: edge of the square tiles, 64 (every kernel) or 128 (vgan_mmd_gram_bf3 only), or 256 = tiles of 256 rows x 128 columns
+ * (vgan_mmd_gram_bf3's loader-wave kernel; a symmetric block then keeps the two tiles of each 256 x 256 diagonal square whole and
+ * mirrors / counts twice only the tiles outside it).
+ * Row-sharded ranks (world > 1): (own Y rows) x (all columns) for the XY and YY blocks -- inside the rank's own diagonal YY block
+ * the upper triangle with mirrored stores, when the block sits on the tile grid -- and, for the X-X block (sums only, no row
+ * ownership), every world-th tile of the WHOLE block's upper triangle.
  * Returns the number of tiles (or -1 if cap is too small); out may be NULL to query the count. */
 int vgan_mmd_build_tiles(int n, int grad_mode, int rank, int world, int tile, int32_t* out, int cap);
 /* Re-applies the XCD-aware launch order (Morton curve, dealt to the 8 XCDs in contiguous chunks) to a table the caller
@@ -255,8 +260,9 @@ int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, uint16_t* Zh,
                          uint16_t* ZTh, uint16_t* ZTl, int kn, vgan_stream_t stream);
 /* vgan_mmd_gram_colmax on the split operands; the gradient weights leave as a bf16 hi/lo pair Wh, Wl
  * [nr, ldw] (ldw >= 2n rounded up to 64; columns >= 2n must be pre-zeroed).  S may be NULL (no column job).
- * tile = the edge the table was built with: 64, or 128 (512-thread workgroups, half the L2->LDS bytes per
- * flop; pays when the table still has >~ 128 tiles). */
+ * tile = the edge the table was built with: 64, 128 (512-thread workgroups, half the L2->LDS bytes per flop; pays when the
+ * table still has >~ 128 tiles) or 256 (256 x 128 tiles, 768-thread workgroups of 8 consumer + 4 loader waves, three K stages
+ * of 32 in LDS, v_mfma_f32_16x16x32_bf16: c4 / c5 sizes). */
 int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
                       const int32_t* tiles, int ntiles, int tile, uint16_t* Wh, uint16_t* Wl, int ldw,
                       int wrow0, float* partial, const float* S, int lds, int from_softmax, int row_offset,
@@ -264,8 +270,9 @@ int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const floa
 /* vgan_mmd_backward on the split operands: out = 2 (rowsum(W) z - W . Z) * mul with W = Wh + Wl [nr, kn]
  * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue.  splits / slab_stride as in
  * vgan_mmd_backward (slabs of out, summed by the consumer in slab order); mul_shift as there.
- * tile: 0 = chosen by the library (128-wide tiles once they fill the chip twice over), or 64 / 128 to force one. */
-/* host-side query (no launch): the tile edge (64 or 128) vgan_mmd_backward_bf3 uses for this shape and `tile` argument */
+ * tile: 0 = chosen by the library (256 x 128 loader-wave tiles once they fill the chip -- row-major B operand only --, else
+ * 128-wide tiles once they fill it twice over, else 64), or 64 / 128 / 256 to force one. */
+/* host-side query (no launch): the tile edge (64, 128 or 256) vgan_mmd_backward_bf3_rm uses for this shape and `tile` argument */
 int vgan_mmd_backward_bf3_tile(int nr, int p, int splits, int tile);
 int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* ZTh,
                           const uint16_t* ZTl, int kn, int kp, const float* Z, int ldz, int wrow0, int nr,

@@ -932,7 +932,17 @@ class NoKLStepEngine:
             import warnings
             warnings.warn(f"vgan_amd: HIP-graph capture of {steps} training step(s) failed ({type(e).__name__}: {e}); running eager launches")
             torch.cuda.synchronize()
-            return None
+            g = None
+        # Several ranks must take the SAME path from here on (a replayed graph and eager launches issue the same collectives, but
+        # a rank that fell back keeps launching while the others replay 16 steps at a time -- and a capture that failed on one
+        # rank only would otherwise go unnoticed by the rest): agree on the outcome.  A capture executes nothing, so no rank has
+        # a collective of the captured steps in flight here.
+        if self.exchange and self.world > 1:
+            dist = self._collect()
+            ok = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device=self.dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0:
+                g = None
         return g  # capture does not execute: the steps that triggered it still have to run
 
     def _capture(self):
