@@ -27,7 +27,13 @@ struct XXJob {
 
 // One tile per workgroup on 256 threads.  The host launch may use larger workgroups (the mask / projection kernel's have 512
 // threads): the surplus waves return at once -- s_barrier waits on the SURVIVING waves of a workgroup only, so the tile's
-// barriers keep working.  One tile per CU is the point: alone on a CU a tile takes ~7 us, two sharing one ~15 (measured with
+// barriers keep working.  ASSUMPTION, recorded here because the HIP programming model calls a barrier that not every thread of
+// the block reaches undefined: it holds on gfx950 / ROCm 7.2 because an ended wave leaves the workgroup's barrier count, and it
+// is exercised only by the 512- and 1024-thread carriers (mask_forward_bf3_kernel<.., XX>: opt-in; linear_bwd_params_ks_xx: the
+// late X-X tiles when the MMD backward launch has no room).  The DEFAULT carrier, mmd_backward_bf3_kernel<64, true>, has exactly
+// 256 threads: no wave returns early there.  Each carrier has a GPU parity test in the default tier
+// (test_backward_bf3_rowmajor_operand_equals_transposed_operand, test_xx_tiles_*, the VGAN_GRAM_SLOTS-forced step tests); should a
+// compiler change break the early return, let the surplus waves idle THROUGH the tile's barriers instead.  One tile per CU is the point: alone on a CU a tile takes ~7 us, two sharing one ~15 (measured with
 // tile PAIRS per workgroup: the carrying launch went from 9.4 to 18.2 us).  lds: GemmBF3<64>::kLdsBytes.
 __device__ __forceinline__ void xx_tile_body(const XXJob& job, int t, char* lds, float* red /* [4] */) {
     using G = GemmBF3<64>;
