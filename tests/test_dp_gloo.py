@@ -56,7 +56,7 @@ def _worker(rank, world, port, steps, out_dir, mode, overlap=None, front=None, p
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "collapsed"), (4, "collapsed"), (2, "layered")])
+@pytest.mark.parametrize("world,mode", [(2, "collapsed"), (4, "collapsed"), (2, "layered"), (8, "collapsed")])
 def test_row_sharded_dp_matches_single_process(world, mode, tmp_path):
     steps = 20
     mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), mode), nprocs=world, join=True)
@@ -69,7 +69,8 @@ def test_row_sharded_dp_matches_single_process(world, mode, tmp_path):
         assert np.array_equal(o["flat"], outs[0]["flat"])              # replicas stay bit-identical
 
 
-@pytest.mark.parametrize("world,precision,assoc", [(2, "fp32", None), (4, "fp32", "flops"), (2, "bf16x3", None), (4, "bf16x3", None)])
+@pytest.mark.parametrize("world,precision,assoc", [(2, "fp32", None), (4, "fp32", "flops"), (2, "bf16x3", None), (4, "bf16x3", None),
+                                                   (8, "bf16x3", "flops")])
 def test_sharded_front_matches_single_process(world, precision, assoc, tmp_path):
     """front='sharded' (every rank runs generator forward, mask / projection and operand split for ITS
     n/G rows and the ranks all-gather the Y rows, their norms and the column arg-max keys; X-X triangle dealt round-robin,
