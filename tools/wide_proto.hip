@@ -271,6 +271,149 @@ __global__ __launch_bounds__(768, 3) void k_lw(const unsigned short* Zh, const u
     }
 }
 
+// Variant: loader waves + the two consumer groups (waves 0-3, waves 4-7: one wave of each per SIMD) HALF A STAGE APART, two raw
+// barriers per stage: while one group multiplies stage kt the other reads its fragments of stage kt (or kt + 1), so the SIMD's
+// matrix pipe always has exactly one wave on it.
+struct WidePP {
+    static constexpr int BM = 256, BN = 128, BK = 32, NTH = 768, NST = 3;
+    static constexpr int PA = BM * BK * 2, PB = BN * BK * 2, STAGE = 2 * PA + 2 * PB, kLdsBytes = NST * STAGE;
+    typedef char __attribute__((address_space(3))) lds_c;
+    __device__ static __forceinline__ int hsw(int r) { return (-(r >> 2)) & 3; }
+    __device__ static __forceinline__ void bar() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K, char* lds_generic,
+                                               f32x4v (&acc)[4][4]) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int nk = K / BK;  // (>= 3 assumed in this prototype)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (wave >= 8) {
+            __builtin_amdgcn_s_setprio(3);
+            const int lw = wave - 8;
+            const char* src[12];
+            int dst[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int pc = 12 * lw + e;
+                const int part = pc < 16 ? 0 : pc < 32 ? 1 : pc < 40 ? 2 : 3;
+                const int pin = part == 0 ? pc : part == 1 ? pc - 16 : part == 2 ? pc - 32 : pc - 40;
+                const int row = 16 * pin + (lane >> 2);
+                const int c = (lane & 3) ^ hsw(row);
+                const unsigned short* base = part == 0 ? Ah : part == 1 ? Al : part == 2 ? Bh : Bl;
+                const long ld = part < 2 ? lda : ldb;
+                const int g0 = part < 2 ? m0 : n0, lim = part < 2 ? M : N;
+                src[e] = reinterpret_cast<const char*>(base + (long)min(g0 + row, lim - 1) * ld) + 16 * c;
+                dst[e] = (part == 0 ? 0 : part == 1 ? PA : part == 2 ? 2 * PA : 2 * PA + PB) + pin * 1024;
+            }
+            auto fill = [&](int kt) {
+                lds_c* d = lds + (kt % NST) * STAGE;
+#pragma unroll
+                for (int e = 0; e < 12; ++e)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src[e] + 2 * (long)kt * BK),
+                                                     (void __attribute__((address_space(3)))*)(d + dst[e]), 16, 0, 0);
+            };
+            fill(0); fill(1); fill(2);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (24 & 15) | ((24 >> 4) << 14));  // vmcnt(24): stage 0 landed
+            bar();  // P
+            // barriers B(0) .. B(2 nk): before an odd B(j), stage (j + 1) / 2 must have landed; behind it, the buffer of stage
+            // (j - 1) / 2 is free (both groups have read it): stage (j + 5) / 2 goes there
+            for (int j = 0; j <= 2 * nk; ++j) {
+                if (j & 1) {
+                    const int need = (j + 1) / 2, next = (j + 5) / 2;
+#ifndef PP_NOWAIT
+                    if (need < nk) {
+                        if (need + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | 12); else __builtin_amdgcn_s_waitcnt(0x0F70);
+                    }
+#endif
+                    bar();
+                    if (next < nk) fill(next);
+                } else {
+                    bar();
+                }
+            }
+            return;
+        }
+        const int grp = wave >> 2, R = wave >> 1, C = wave & 1;
+        const int fr = lane & 15, fc = lane >> 4;
+        const int posA = (fc ^ hsw(fr)) << 4;
+        u32x4 ah[4], al[4], bh[4], bl[4];
+        auto frags = [&](int kt) {
+            const lds_c* st = lds + (kt % NST) * STAGE;
+            const lds_c* pa = st + (R * 64 + fr) * 64 + posA;
+            const lds_c* pb = st + 2 * PA + (C * 64 + fr) * 64 + posA;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) al[b] = *(const lds_u4*)(pa + PA + b * 1024);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bh[b] = *(const lds_u4*)(pb + b * 1024);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) ah[b] = *(const lds_u4*)(pa + b * 1024);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bl[b] = *(const lds_u4*)(pb + PB + b * 1024);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the reads are done before the barrier that frees the buffer
+        };
+        auto mfmas = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+        };
+        bar();  // P
+        if (grp == 0) {
+            for (int kt = 0; kt < nk; ++kt) {
+                frags(kt);
+                bar();
+                mfmas();
+                bar();
+            }
+            bar();
+        } else {
+            bar();
+            for (int kt = 0; kt < nk; ++kt) {
+                frags(kt);
+                bar();
+                mfmas();
+                bar();
+            }
+        }
+    }
+};
+
+__global__ __launch_bounds__(768, 3) void k_pp(const unsigned short* Zh, const unsigned short* Zl, int kp, int ld, int N, int tiles_per_row, float* out, float* tile0) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int per = gridDim.x / 8, t = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const int blk = t / 32, in = t % 32, bpr = tiles_per_row / 8;
+    const int r0 = ((blk / bpr) * 4 + in / 8) * 256, c0 = ((blk % bpr) * 8 + in % 8) * 128;
+    f32x4v acc[4][4];
+    WidePP::run(Zh, Zl, ld, Zh, Zl, ld, r0, c0, N, N, kp, lds, acc);
+    if (threadIdx.x >= 512) return;
+    float s = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
+    if (r0 == 0 && c0 == 128 && tile0 != nullptr) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, R = wave >> 1, C = wave & 1;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r)
+            tile0[(64 * R + 16 * i + 4 * (lane >> 4) + r) * 128 + 64 * C + 16 * j + (lane & 15)] = acc[i][j][r];
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void k_big(const unsigned short* Zh, const unsigned short* Zl, int kp, int ld, int N, int tiles_per_row, float* out) {
     using G = GemmBF3Big;
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
@@ -299,6 +442,7 @@ int main(int argc, char** argv) {
     hipMemcpy(Zl, hl.data(), hl.size() * 2, hipMemcpyHostToDevice);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<Wide>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<false, true, true>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<true, false, true>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<false, true, false>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
@@ -325,10 +469,14 @@ int main(int argc, char** argv) {
     std::vector<float> t1(256 * 128);
     hipMemcpy(t1.data(), tile0, t1.size() * 4, hipMemcpyDeviceToHost);
     printf("loader-wave variant equals the plain wide loop bit for bit: %s\n", memcmp(t0.data(), t1.data(), t0.size() * 4) == 0 ? "yes" : "NO");
+    hipMemset(tile0, 0, 256 * 128 * 4);
+    hipLaunchKernelGGL(k_pp, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, tile0);
+    hipMemcpy(t1.data(), tile0, t1.size() * 4, hipMemcpyDeviceToHost);
+    printf("staggered-group variant equals the plain wide loop bit for bit: %s\n", memcmp(t0.data(), t1.data(), t0.size() * 4) == 0 ? "yes" : "NO");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
-        const char* names[] = {"big 128x128x64 (2 st)", "wide 256x128x32 (3 st)", "wide, no fill", "wide, no MFMA", "wide, MFMA only", "wide, fill only", "wide + 4 loader waves"};
-        for (int which = 0; which < 7; ++which) {
+        const char* names[] = {"big 128x128x64 (2 st)", "wide 256x128x32 (3 st)", "wide, no fill", "wide, no MFMA", "wide, MFMA only", "wide, fill only", "wide + 4 loader waves", "loaders + staggered groups"};
+        for (int which = 0; which < 8; ++which) {
             auto launch = [&]() {
                 float* nul = nullptr;
                 if (which == 0) hipLaunchKernelGGL(k_big, dim3(ntB), dim3(512), 0, 0, Zh, Zl, kp, ld, N, tprB, out);
@@ -337,7 +485,8 @@ int main(int argc, char** argv) {
                 else if (which == 3) hipLaunchKernelGGL((k_wide<WideT<true, false, true>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
                 else if (which == 4) hipLaunchKernelGGL((k_wide<WideT<false, true, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
                 else if (which == 5) hipLaunchKernelGGL((k_wide<WideT<true, false, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
-                else hipLaunchKernelGGL(k_lw, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else if (which == 6) hipLaunchKernelGGL(k_lw, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else hipLaunchKernelGGL(k_pp, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
             };
             for (int i = 0; i < 10; ++i) launch();
             hipEventRecord(e0);

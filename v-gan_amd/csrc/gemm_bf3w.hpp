@@ -14,6 +14,7 @@
 //     0.68-0.70 for the bare MFMA loops) and 4 LOADER waves that issue the whole fill (12 one-KB global_load_lds pieces each per
 //     stage), own the vmcnt waits and run at raised priority.  A consumer never issues a DMA (~100 cycles of issue each
 //     inside a busy phase) and never waits on vmcnt: 0.53 -> 0.57-0.61 on the same box, bit-identical results;
+//   * the two consumer groups (waves 0-3, 4-7) run half a stage apart (two barriers per stage: `consumers` below), +2.7 %;
 //   * the loaders also take the row sums of A the backward product needs, from the landed LDS image (they are idle otherwise).
 // Same box, binaries alternated, ten warm-up launches: 0.595-0.610 of the nominal 2.5 PFLOP/s executed against 0.512-0.517 for
 // GemmBF3Big (+17-19 %).
@@ -127,7 +128,20 @@ struct GemmBF3Wide {
         return s + s2;
     }
 
-    // The loader wave's whole life inside the main loop.  SIDE_A: rs[256] (LDS floats) = sum_k A[m0 + m, k].
+    // Schedule of a tile (prototype: tools/wide_proto.hip, WidePP: 0.615-0.623 against 0.600-0.605 with all eight consumers in
+    // lockstep, bit-identical).  The consumer waves form two GROUPS, waves 0-3 and 4-7 -- one wave of each on every SIMD -- that run
+    // HALF A STAGE APART behind two raw barriers per stage: while one group multiplies a stage the other reads its fragments, so a
+    // SIMD's matrix pipe always has exactly one wave on it instead of two waves reading together and then sharing the pipe.
+    // After the prologue barrier P the barriers are B(0) .. B(2 nk):
+    //   group 0:  [read kt] B(2 kt) [multiply kt] B(2 kt + 1) ...              and one closing barrier;
+    //   group 1:  B(0), then [read kt] B(2 kt + 1) [multiply kt] B(2 kt + 2) ...
+    //   loaders:  stage kt must have landed before B(2 kt - 1) (group 0 reads it behind that barrier) and its buffer is free
+    //             behind B(2 kt + 1) (both groups have read it): stage kt + 3 is issued there -- two stages in flight.
+    __device__ static __forceinline__ void wait_landed(bool younger_in_flight) {
+        if (younger_in_flight) __builtin_amdgcn_s_waitcnt(0x0F70 | 12); else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(12) / vmcnt(0)
+    }
+
+    // The loader wave's whole life inside a tile.  SIDE_A: rs[256] (LDS floats) = sum_k A[m0 + m, k].
     template <bool RM, bool SIDE_A>
     __device__ static __forceinline__ void loader(const Fill<RM>& fl, lds_c* lds, int nk, float* rs_generic) {
         __builtin_amdgcn_s_setprio(3);
@@ -135,19 +149,73 @@ struct GemmBF3Wide {
         float rsum = 0.f;
         fl.issue(lds, 0);
         if (nk > 1) fl.issue(lds, 1);
-        if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 12); else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(12): stage 0 landed
-        bar();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 2 < nk) fl.issue(lds, kt + 2);   // into the buffer of stage kt - 1: its readers passed the last barrier
-            if constexpr (SIDE_A) rsum = row_part(lds + (kt % NST) * STAGE, 64 * lw + lane, rsum);
-            // stage kt + 1 must have landed before the barrier lets anyone read it; stage kt + 2 (the 12 youngest) stays in flight
-            if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | 12); else __builtin_amdgcn_s_waitcnt(0x0F70);
-            bar();
+        if (nk > 2) fl.issue(lds, 2);
+        if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (24 & 15) | ((24 >> 4) << 14));  // vmcnt(24): stage 0 has landed
+        else wait_landed(nk > 1);
+        bar();  // P
+        if constexpr (SIDE_A) rsum = row_part(lds, 64 * lw + lane, rsum);  // stage 0 (its buffer lives until B(1))
+        for (int j = 0; j <= 2 * nk; ++j) {
+            if (j & 1) {
+                const int need = (j + 1) >> 1, next = (j + 5) >> 1;
+                if (need < nk) wait_landed(need + 1 < nk);
+                bar();
+                if (next < nk) fl.issue(lds, next);  // into the buffer of stage next - 3, read for the last time before this barrier
+                if constexpr (SIDE_A)
+                    if (need < nk) rsum = row_part(lds + (need % NST) * STAGE, 64 * lw + lane, rsum);  // lives until B(j + 2)
+            } else {
+                bar();
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         if constexpr (SIDE_A) ((lds_f*)rs_generic)[64 * lw + lane] = rsum;
     }
 
+    // the consumer waves' two-group schedule around `frags(kt)` (fragment reads of stage kt, drained) and `mfmas()`
+    template <class FragF, class MfmaF>
+    __device__ static __forceinline__ void consumers(int grp, int nk, FragF frags, MfmaF mfmas) {
+        bar();  // P
+        if (grp == 0) {
+            for (int kt = 0; kt < nk; ++kt) {
+                frags(kt);
+                bar();
+                mfmas();
+                bar();
+            }
+            bar();
+        } else {
+            bar();
+            for (int kt = 0; kt < nk; ++kt) {
+                frags(kt);
+                bar();
+                mfmas();
+                bar();
+            }
+        }
+    }
+
+    // The LOCKSTEP schedule (one barrier per stage, all eight consumers in the same phase), kept for the backward product: its
+    // loaders also form the row sums, and with two barriers per stage that work sits between two barriers the consumers wait at
+    // -- same box, alternating: backward 2.99-3.04 ms staggered against 2.85-2.87 lockstep at c5 (the Gram, whose loaders only
+    // load, gains: 2.74-2.77 against 2.79-2.81).
+    template <bool RM, bool SIDE_A>
+    __device__ static __forceinline__ void loader_lockstep(const Fill<RM>& fl, lds_c* lds, int nk, float* rs_generic) {
+        __builtin_amdgcn_s_setprio(3);
+        const int lane = threadIdx.x & 63, lw = (threadIdx.x - NCONS) >> 6;
+        float rsum = 0.f;
+        fl.issue(lds, 0);
+        if (nk > 1) fl.issue(lds, 1);
+        wait_landed(nk > 1);  // stage 0 has landed
+        bar();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 < nk) fl.issue(lds, kt + 2);   // into the buffer of stage kt - 1: its readers passed the last barrier
+            if constexpr (SIDE_A) rsum = row_part(lds + (kt % NST) * STAGE, 64 * lw + lane, rsum);
+            // stage kt + 1 must have landed before the barrier lets anyone read it; stage kt + 2 (the 12 youngest) stays in flight
+            wait_landed(kt + 2 < nk);
+            bar();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (SIDE_A) ((lds_f*)rs_generic)[64 * lw + lane] = rsum;
+    }
     // the 48 MFMAs of a stage: three products per 16 x 16 block, small terms first
     __device__ static __forceinline__ void mac(f32x4w (&acc)[4][4], const bf16x8 (&xh)[4], const bf16x8 (&xl)[4], const bf16x8 (&yh)[4],
                                                const bf16x8 (&yl)[4], bool first_only, bool rest_only) {
@@ -168,6 +236,7 @@ struct GemmBF3Wide {
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[i], yh[j], acc[i][j], 0, 0, 0);
     }
 
+
     // acc[i][j] (+)= (A[m0 .., :] . B[n0 .., :]^T) over K (a multiple of 32), block (i, j) of this consumer wave's quadrant:
     // element r of acc[i][j] is row sub_row(i, r), column sub_col(j).  All 768 threads call; loader threads come back with acc
     // untouched.  Ends with one __syncthreads(): the LDS is free for the caller's epilogue.
@@ -186,38 +255,22 @@ struct GemmBF3Wide {
             const int R = wave >> 1, C = wave & 1;
             const int fr = lane & 15, fc = lane >> 4;
             const int pos = (fc ^ hsw(fr)) << 4;  // rows 16 b + fr: (row >> 2) & 3 = (fr >> 2) & 3 for every block b
-            u32x4 ah[4], al[4], bh[4], bl[4];
-            bar();
-            for (int kt = 0; kt < nk; ++kt) {
+            bf16x8 xh[4], xl[4], yh[4], yl[4];
+            auto frags = [&](int kt) {
                 const lds_c* st = lds + (kt % NST) * STAGE;
                 const lds_c* pa = st + (R * 64 + fr) * 64 + pos;
                 const lds_c* pb = st + 2 * PA + (C * 64 + fr) * 64 + pos;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) al[b] = *(const lds_u4*)(pa + PA + b * 1024);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) bh[b] = *(const lds_u4*)(pb + b * 1024);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) ah[b] = *(const lds_u4*)(pa + b * 1024);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) bl[b] = *(const lds_u4*)(pb + PB + b * 1024);
-                bf16x8 xh[4], xl[4], yh[4], yl[4];
-#pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    xh[b] = __builtin_bit_cast(bf16x8, ah[b]);
-                    xl[b] = __builtin_bit_cast(bf16x8, al[b]);
-                    yh[b] = __builtin_bit_cast(bf16x8, bh[b]);
-                    yl[b] = __builtin_bit_cast(bf16x8, bl[b]);
+                    xl[b] = __builtin_bit_cast(bf16x8, *(const lds_u4*)(pa + PA + b * 1024));
+                    yh[b] = __builtin_bit_cast(bf16x8, *(const lds_u4*)(pb + b * 1024));
+                    xh[b] = __builtin_bit_cast(bf16x8, *(const lds_u4*)(pa + b * 1024));
+                    yl[b] = __builtin_bit_cast(bf16x8, *(const lds_u4*)(pb + PB + b * 1024));
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8));  // lgkmcnt(8): al, bh are here -- the first product starts
-                __builtin_amdgcn_sched_barrier(0);
-                mac(acc, xh, xl, yh, yl, true, false);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0)
-                __builtin_amdgcn_sched_barrier(0);
-                mac(acc, xh, xl, yh, yl, false, true);
-                bar();
-            }
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): read before the barrier that lets the buffer go
+            };
+            auto mfmas = [&]() { mac(acc, xh, xl, yh, yl, false, false); };
+            consumers(wave >> 2, nk, frags, mfmas);
         }
         __syncthreads();
     }
@@ -234,7 +287,7 @@ struct GemmBF3Wide {
         if (wave >= 8) {
             Fill<true> fl;
             fl.init(wave - 8, lane, Ah, Al, lda, m0, M, Bh, Bl, ldb, n0, ncols, zrows);
-            loader<true, SIDE_A>(fl, lds, nk, rs_generic);
+            loader_lockstep<true, SIDE_A>(fl, lds, nk, rs_generic);
         } else {
             const int R = wave >> 1, C = wave & 1;
             const int fr = lane & 15, fc = lane >> 4;
@@ -248,29 +301,24 @@ struct GemmBF3Wide {
                 const int row = 8 * g + qq, chunk = 2 * (4 * C + j) + (pp >> 1);
                 offB[j] = row * 256 + ((chunk ^ tsw(row)) << 4) + (pp & 1) * 8;  // (tsw(row + 4) = tsw(row): bit 2 is not in it)
             }
-            u32x4 ah[4], al[4];
-            bf16x8 yh[4], yl[4];
+            bf16x8 xh[4], xl[4], yh[4], yl[4];
+            // lockstep schedule; the fragment reads are ordered so that the first product (xl . yh) starts when HALF of them
+            // have landed
             bar();
             for (int kt = 0; kt < nk; ++kt) {
                 const lds_c* st = lds + (kt % NST) * STAGE;
                 const lds_c* pa = st + (R * 64 + fr) * 64 + pos;
                 const lds_c* pb = st + 2 * PA;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) al[b] = *(const lds_u4*)(pa + PA + b * 1024);
+                for (int b = 0; b < 4; ++b) xl[b] = __builtin_bit_cast(bf16x8, *(const lds_u4*)(pa + PA + b * 1024));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) yh[j] = tr_read_k8(pb + offB[j], 1024);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) ah[b] = *(const lds_u4*)(pa + b * 1024);
+                for (int b = 0; b < 4; ++b) xh[b] = __builtin_bit_cast(bf16x8, *(const lds_u4*)(pa + b * 1024));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) yl[j] = tr_read_k8(pb + PB + offB[j], 1024);
-                bf16x8 xh[4], xl[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    xh[b] = __builtin_bit_cast(bf16x8, ah[b]);
-                    xl[b] = __builtin_bit_cast(bf16x8, al[b]);
-                }
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xC07F | (12 << 8));  // lgkmcnt(12): al (4) and yh (8 reads) are here
+                __builtin_amdgcn_s_waitcnt(0xC07F | (12 << 8));  // lgkmcnt(12): xl (4) and yh (8 reads) are here
                 __builtin_amdgcn_sched_barrier(0);
                 mac(acc, xh, xl, yh, yl, true, false);
                 __builtin_amdgcn_sched_barrier(0);
