@@ -109,11 +109,17 @@ def run_steps(eng, count, start_step):
     from vgan_amd.vgan import epoch_batches
     t, end = start_step, start_step + count
     while t < end:
-        if t % EPOCH_BATCHES == 0:  # new shuffled epoch, as fit() does
+        if t % EPOCH_BATCHES == 0 and os.environ.get("VGAN_FEED_DIRECT") == "1":
             eng.set_epoch_batches(epoch_batches(eng.data.shape[0], N_BATCH))
+        elif t % EPOCH_BATCHES == 0:  # new shuffled epoch, as fit() does: the table was drawn and uploaded behind the previous steps
+            if not eng.epoch_staged:
+                eng.stage_epoch_batches(epoch_batches(eng.data.shape[0], N_BATCH))
+            eng.begin_epoch()
         k = min(end - t, EPOCH_BATCHES - t % EPOCH_BATCHES)
         eng.run_steps(k)
         t += k
+        if not eng.epoch_staged and os.environ.get("VGAN_FEED_DIRECT") != "1":  # the next epoch's table, while the GPU works through these steps (NoKLStepEngine.stage_epoch_batches)
+            eng.stage_epoch_batches(epoch_batches(eng.data.shape[0], N_BATCH))
 
 
 def time_kernel(fn, iters=30, repeats=5):
@@ -177,7 +183,7 @@ def kernel_rooflines(eng):
         nt = eng.tiles.shape[0] if eng.front_sharded else eng.n_main
         main_flop = 2.0 * D_FEAT * pairs_of(tl[:nt])
         ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[:nt], eng.Wh, eng.Wl, n + lo, eng.partial,
-                                                  tile=eng.gram_tile), iters)
+                                                  tile=eng.gram_tile, tail_ws=eng.gram_tail_ws), iters)
         out[gname] = {"ms": ms, "tflops": main_flop / (ms * 1e-3) / 1e12, "flop": main_flop, "tiles": int(nt)}
         if nt < eng.tiles.shape[0]:
             xx_flop = 2.0 * D_FEAT * pairs_of(tl[nt:])

@@ -27,7 +27,7 @@ extern "C" {
 #define VGAN_ERR_ARG 1  /* bad shape / null pointer / unsupported configuration */
 #define VGAN_ERR_HIP 2  /* a HIP runtime call or launch failed */
 
-#define VGAN_ABI_VERSION 5
+#define VGAN_ABI_VERSION 6
 
 typedef void* vgan_stream_t; /* hipStream_t */
 
@@ -262,11 +262,20 @@ int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, uint16_t* Zh,
  * [nr, ldw] (ldw >= 2n rounded up to 64; columns >= 2n must be pre-zeroed).  S may be NULL (no column job).
  * tile = the edge the table was built with: 64, 128 (512-thread workgroups, half the L2->LDS bytes per flop; pays when the
  * table still has >~ 128 tiles) or 256 (256 x 128 tiles, 768-thread workgroups of 8 consumer + 4 loader waves, three K stages
- * of 32 in LDS, v_mfma_f32_16x16x32_bf16: c4 / c5 sizes). */
+ * of 32 in LDS, v_mfma_f32_16x16x32_bf16: c4 / c5 sizes).
+ * tail_ws (may be NULL; read only with tile = 256): device workspace of at least vgan_mmd_gram_bf3_tail_ws_bytes() bytes,
+ * 16-byte aligned, whose last 4 096 bytes are ZERO before the first launch that uses it (the launches keep them zero) and
+ * which no other launch uses concurrently.  With it, a table whose last round would leave at least half of the CUs idle (one
+ * 768-thread workgroup holds a CU: ntiles mod CUs <= CUs / 2) has the tiles of that round computed by 2 or 4 workgroups
+ * each, split over K; the partial products meet in the workspace and the last workgroup to arrive finishes the tile (sums in
+ * part order: deterministic; nobody waits on anybody).  Results then differ from the unsplit launch by fp32 summation order
+ * in those tiles only. */
+int64_t vgan_mmd_gram_bf3_tail_ws_bytes(void);
 int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
                       const int32_t* tiles, int ntiles, int tile, uint16_t* Wh, uint16_t* Wl, int ldw,
                       int wrow0, float* partial, const float* S, int lds, int from_softmax, int row_offset,
-                      uint64_t* colpart, int nrows, int d, vgan_stream_t stream);
+                      uint64_t* colpart, int nrows, int d, void* tail_ws, int64_t tail_ws_bytes,
+                      vgan_stream_t stream);
 /* vgan_mmd_backward on the split operands: out = 2 (rowsum(W) z - W . Z) * mul with W = Wh + Wl [nr, kn]
  * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue.  splits / slab_stride as in
  * vgan_mmd_backward (slabs of out, summed by the consumer in slab order); mul_shift as there.

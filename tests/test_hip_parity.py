@@ -1302,6 +1302,51 @@ def test_gram_bf3_tile128_equals_tile64(ops, n, d, mode):
         assert float((a[1] != b[1]).double().mean()) < 1e-3, tile  # hi halves differ only where w sits on a bf16 rounding boundary
 
 
+@pytest.mark.parametrize("n,d,mode,parts", [(1024, 520, 1, 2), (512, 4096, 2, 4), (640, 1030, 1, 4), (2304, 512, 1, 2)])
+def test_gram_bf3_wide_tail_split(ops, n, d, mode, parts):
+    """tile = 256 with the tail workspace (include/vgan_hip.h, tail_ws): the tiles of a short last round are computed by 2 or 4
+    workgroups each, split over K, and finished by the last one to arrive.  Against the same launch without workspace:
+    block sums and gradient weights to fp32 summation order, identical column keys, every W element written; the same bits
+    launch after launch (the sums run in part order, whoever arrives last) and the tickets back at zero.  (2304, 512): 342 tiles =
+    one full round of 256 + 86 split in two; the others have a single short round.)"""
+    rng = np.random.default_rng(n + d)
+    Zf = torch.as_tensor((rng.normal(size=(2 * n, d)) * (6.0 / np.sqrt(d))).astype(np.float32)).cuda()
+    S = torch.as_tensor(rng.uniform(0, 2.0 / d, size=(n, d)).astype(np.float32)).cuda()
+    sq = torch.empty(2 * n, device="cuda")
+    ops.row_sqnorm(Zf, sq, d)
+    kp, kn = (d + 63) // 64 * 64, (2 * n + 63) // 64 * 64
+    i16 = dict(dtype=torch.int16, device="cuda")
+    Zh, Zl = torch.zeros(2 * n, kp, **i16), torch.zeros(2 * n, kp, **i16)
+    ops.mmd_bf3_prepare(Zf, 2 * n, d, Zh, Zl)
+    bw = torch.full((1,), 30.0, device="cuda")  # |z_i - z_j|^2 ~ 72 whatever d: kernels well inside (0, 1)
+    nr, wrow0 = (n, n) if mode == 1 else (2 * n, 0)
+    tiles = ops.build_tiles(n, mode, tile=256)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    r = tiles.shape[0] % min(cus, 256)
+    assert 0 < r and parts * r <= min(cus, 256) and kp // 32 // parts >= 8, "the case does not split the way its name says"
+    ws = ops.gram_tail_workspace("cuda")
+    res = []
+    for tail in (None, ws, ws, ws):
+        partial = torch.zeros(tiles.shape[0], 4, device="cuda")
+        Wh, Wl = torch.full((nr, kn), 0x7FC0, **i16), torch.full((nr, kn), 0x7FC0, **i16)
+        colpart = torch.zeros(ops.colmax_chunks(n) * d, dtype=torch.int64, device="cuda")
+        ops.mmd_gram_bf3(Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S, 0, colpart, True, tile=256, tail_ws=tail)
+        stats = torch.zeros(4, dtype=torch.float64, device="cuda")
+        ops.mmd_reduce(partial, tiles, stats, True)
+        res.append((host(stats), Wh[:, :2 * n].clone(), Wl[:, :2 * n].clone(), colpart.clone(), partial.clone()))
+    assert int(ws[-1024:].abs().sum()) == 0, "tickets not reset"
+    val = lambda h, l: (h.to(torch.int32) << 16).view(torch.float32).double() + (l.to(torch.int32) << 16).view(torch.float32).double()
+    a, b = res[0], res[1]
+    np.testing.assert_allclose(a[0][:3], b[0][:3], rtol=1e-6)
+    assert torch.equal(a[3], b[3])
+    assert not bool((b[1] == 0x7FC0).any()), "part of W left unwritten"
+    wa, wb = val(a[1], a[2]), val(b[1], b[2])
+    assert float((wa - wb).abs().max()) <= 5e-5 * float(wa.abs().max())
+    assert not torch.equal(a[4], b[4]) or parts == 1, "the split launch did not split (same bits as the whole tiles)"
+    for c in res[2:]:
+        assert torch.equal(b[1], c[1]) and torch.equal(b[2], c[2]) and torch.equal(b[4], c[4]), "split launch not reproducible"
+
+
 @pytest.mark.parametrize("n,d,nr_of,splits", [(512, 1000, 1, 2), (300, 130, 2, 1), (1024, 2048, 1, 4), (200, 64, 1, 3)])
 def test_backward_bf3_wide_tiles(ops, n, d, nr_of, splits):
     """vgan_mmd_backward_bf3_rm on 256 x 128 output tiles (GemmBF3Wide::run_bt: 8 consumer + 4 loader waves, B fragments by

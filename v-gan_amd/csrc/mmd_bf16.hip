@@ -309,18 +309,25 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
                                                                    const float* __restrict__ bw_ptr, const TileDesc* __restrict__ tiles,
                                                                    int ntiles, unsigned short* __restrict__ Wh,
                                                                    unsigned short* __restrict__ Wl, int ldw, int wrow0,
-                                                                   float* __restrict__ partial, ColmaxJob cj) {
+                                                                   float* __restrict__ partial, ColmaxJob cj, TailSplit ts) {
     using G = GemmBF3Wide;
     constexpr int LDT = 132, LDM = 260;  // epilogue images Wt[256][LDT] (direct) and WtT[128][LDM] (mirrored), one at a time
     static_assert(256 * LDT * 4 <= G::kLdsBytes && 128 * LDM * 4 <= G::kLdsBytes, "epilogue images reuse the stage buffers");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     __shared__ float red[12];
-    if ((int)blockIdx.x >= ntiles) {
-        const int cb = blockIdx.x - ntiles;
+    __shared__ int last_part;
+    const int nblk = ts.first + (ntiles - ts.first) * ts.parts;  // whole tiles, then `parts` workgroups per tail tile
+    if ((int)blockIdx.x >= nblk) {
+        const int cb = blockIdx.x - nblk;
         colmax_partial_body<12>(cj.S, cj.lds, cj.row_offset, cj.part, cj.n, cj.d, cj.from_softmax, cb % cj.nbx, cb / cj.nbx);
         return;
     }
-    const TileDesc td = tiles[blockIdx.x];
+    const bool split = (int)blockIdx.x >= ts.first;
+    const int tq = split ? ((int)blockIdx.x - ts.first) / ts.parts : 0;
+    const int ti = split ? ts.first + tq : (int)blockIdx.x;
+    const int part = split ? ((int)blockIdx.x - ts.first) - tq * ts.parts : 0;
+    const int k0 = part * ts.kchunk, klen = split ? min(ts.kchunk, kp - k0) : kp;
+    const TileDesc td = tiles[ti];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool cons = !G::is_loader();
     // epilogue operands requested before the main loop (see mmd_gram_bf3_kernel); loader threads clamp to the tile's corner
@@ -337,7 +344,51 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4w{0.f, 0.f, 0.f, 0.f};
-    G::run<false>(Zh, Zl, kp, Zh, Zl, kp, td.r0, td.c0, td.rlim, td.clim, kp, lds, acc);
+    G::run<false>(Zh + k0, Zl + k0, kp, Zh + k0, Zl + k0, kp, td.r0, td.c0, td.rlim, td.clim, klen, lds, acc);
+    if (split) {
+        // One K part of a tail tile: the partial products go to this part's slab (thread-linear: block (i, j) of consumer thread
+        // t at 16-byte index (4 i + j) * 512 + t), the LAST part to arrive sums all slabs in part order -- its own included, so
+        // the result does not depend on who came last -- and runs the epilogue.  Nobody waits for anybody: no residency
+        // assumption.  No fences either: a release / acquire fence is an L2-wide write-back / invalidate per WAVE, and 3 072 of
+        // them at the end of a launch whose L2s are full of dirty W lines cost more than the round they were to save (c4: Gram
+        // 0.40 -> 0.50 ms, measured).  Instead the slabs move with sc0 sc1 (write-through / coherent) stores and loads, each
+        // storing thread drains its stores (vmcnt(0)) before the workgroup's relaxed device-scope ticket: MI355X_MICROARCH.md,
+        // "publish-large".
+        const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc(ts.slabs, 0, (int)(kTailSlabs * kTailSlabBytes), 0x00020000);
+        constexpr int kCoherent = 17;  // aux: sc0 | sc1
+        const int slab0 = tq * ts.parts * (int)kTailSlabBytes;
+        if (cons) {
+            const int mine = slab0 + part * (int)kTailSlabBytes + threadIdx.x * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), slabs, mine + (4 * i + j) * (G::NCONS * 16), 0, kCoherent);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(ts.tickets + tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_part = old == ts.parts - 1;
+            if (old == ts.parts - 1) __hip_atomic_store(ts.tickets + tq, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+        }
+        __syncthreads();
+        if (!last_part) return;
+        if (cons) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4w{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < ts.parts; ++q) {
+                const int theirs = slab0 + q * (int)kTailSlabBytes + threadIdx.x * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] += __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(slabs, theirs + (4 * i + j) * (G::NCONS * 16), 0, kCoherent));
+            }
+        }
+    }
 
     const float c2 = -1.4426950408889634f / (4.f * bw);
     const float wscale = -((td.flags & VGAN_TF_NEG) ? -1.f : 1.f) * 2.f / ((float)n * (float)n * bw);
@@ -436,7 +487,7 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
     if (lane == 0) red[wave] = ksum;
     __syncthreads();
     if (threadIdx.x == 0)
-        reinterpret_cast<float4*>(partial)[blockIdx.x] =
+        reinterpret_cast<float4*>(partial)[ti] =
             make_float4(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])), 0.f, 0.f, 0.f);
 }
 
@@ -647,10 +698,15 @@ extern "C" int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, ui
     return VGAN_OK;
 }
 
+#ifndef VGAN_TAIL_MAX_PARTS
+#define VGAN_TAIL_MAX_PARTS 4
+#endif
+extern "C" int64_t vgan_mmd_gram_bf3_tail_ws_bytes(void) { return kTailSlabs * kTailSlabBytes + kTailTicketBytes; }
+
 extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
                                  const int32_t* tiles, int ntiles, int tile, uint16_t* Wh, uint16_t* Wl, int ldw, int wrow0,
                                  float* partial, const float* S, int lds, int from_softmax, int row_offset, uint64_t* colpart,
-                                 int nrows, int d, vgan_stream_t stream) {
+                                 int nrows, int d, void* tail_ws, int64_t tail_ws_bytes, vgan_stream_t stream) {
     VGAN_CHECK_ARG(Zh && Zl && sq && bw && tiles && partial && n > 0 && ntiles > 0 && kp > 0 && kp % 64 == 0);
     VGAN_CHECK_ARG((Wh == nullptr) == (Wl == nullptr) && (reinterpret_cast<uintptr_t>(partial) & 15) == 0);
     VGAN_CHECK_ARG(aligned16(Zh) && aligned16(Zl) && (Wh == nullptr || (aligned16(Wh) && aligned16(Wl))));
@@ -666,8 +722,29 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_gram_bf3_wide_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, GemmBF3Wide::kLdsBytes);
         VGAN_CHECK_ARG(attr == hipSuccess);
-        hipLaunchKernelGGL(mmd_gram_bf3_wide_kernel, dim3(ntiles + extra), dim3(GemmBF3Wide::NTH), GemmBF3Wide::kLdsBytes, (hipStream_t)stream, Zh,
-                           Zl, kp, sq, n, bw, reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
+        // a short last round is split over K (TailSplit, mmd_common.hpp) when the caller lends the workspace
+        TailSplit ts{nullptr, nullptr, ntiles, 1, kp};
+        if (tail_ws != nullptr) {
+            VGAN_CHECK_ARG(tail_ws_bytes >= vgan_mmd_gram_bf3_tail_ws_bytes() && aligned16(tail_ws));
+            static const int cus = [] {
+                int dev = 0, v = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+                return v;
+            }();
+            const int slots = cus < kTailSlabs ? cus : kTailSlabs;
+            const int r = slots > 0 ? ntiles % slots : 0, nst = kp / GemmBF3Wide::BK;
+            int parts = 1;  // the largest of 2, 4 that keeps the tail in one round and a part at least 8 stages long (8 parts measured
+                            // slower at c4: 32 tiles x 8 slabs of 128 KB written and read back inside ~20 us)
+            while (r > 0 && parts < VGAN_TAIL_MAX_PARTS && 2 * parts * r <= slots && nst / (2 * parts) >= 8) parts *= 2;
+            if (parts > 1) {
+                const int kchunk = ((nst + parts - 1) / parts) * GemmBF3Wide::BK;
+                ts = TailSplit{static_cast<float*>(tail_ws), reinterpret_cast<int*>(static_cast<char*>(tail_ws) + kTailSlabs * kTailSlabBytes),
+                               ntiles - r, (kp + kchunk - 1) / kchunk, kchunk};
+            }
+        }
+        const int nblk = ts.first + (ntiles - ts.first) * ts.parts;
+        hipLaunchKernelGGL(mmd_gram_bf3_wide_kernel, dim3(nblk + extra), dim3(GemmBF3Wide::NTH), GemmBF3Wide::kLdsBytes, (hipStream_t)stream, Zh,
+                           Zl, kp, sq, n, bw, reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj, ts);
     } else if (tile == 128)
         hipLaunchKernelGGL(mmd_gram_bf3_big_kernel, dim3(ntiles + extra), dim3(512), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
                            reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);

@@ -18,6 +18,20 @@ struct ColmaxJob {
     int lds, row_offset, n, d, from_softmax, nbx;  // nbx = ceil(d / 64); job is empty when S == nullptr
 };
 
+// K split of the LAST tiles of a wide Gram launch (vgan_mmd_gram_bf3, tile = 256): one 768-thread workgroup holds a CU, so a
+// table of T tiles runs in ceil(T / CUs) rounds and a short last round idles most of the chip for a whole tile time (c4: 1 040
+// tiles on 256 CUs = 4 rounds + 16 tiles).  Tiles [first, ntiles) are therefore computed by `parts` workgroups each, part q over
+// K columns [q kchunk, (q + 1) kchunk); the partial products meet in `slabs` (one 128 KB slab per part) and the last part to
+// arrive at the tile's ticket finishes the tile.  first = ntiles, parts = 1: no split.
+struct TailSplit {
+    float* slabs;
+    int* tickets;  // one per split tile, zero between launches (the finishing workgroup resets it)
+    int first, parts, kchunk;
+};
+constexpr int kTailSlabs = 256;                       // at most this many parts per launch
+constexpr long kTailSlabBytes = 256L * 128 * 4;       // one part's partial products
+constexpr long kTailTicketBytes = 4096;               // tickets sit behind the slabs
+
 
 // The single-rank step tail (vgan_mmd_finalize): partial[] -> stats[4]; colpart[chunks * d] -> colkey[d]; loss and its
 // bookkeeping.  Runs in one workgroup of any size up to 1024 threads: stand-alone (mmd_finalize_kernel) or as the

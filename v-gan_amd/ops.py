@@ -328,15 +328,20 @@ class HipOps:
         _lib.check(self.lib.vgan_mmd_bf3_prepare(_ptr(Z), Z.stride(0), int(rows), int(p), _ptr(Zh), _ptr(Zl), Zh.stride(0),
                                                  _ptr(ZTh), _ptr(ZTl), kn, self._stream()), "vgan_mmd_bf3_prepare")
 
+    def gram_tail_workspace(self, device):
+        """Workspace a tile-256 mmd_gram_bf3 launch splits its last round in (include/vgan_hip.h: tail_ws); zeroed once here."""
+        return torch.zeros(int(self.lib.vgan_mmd_gram_bf3_tail_ws_bytes()) // 4, dtype=torch.int32, device=device)
+
     def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True,
-                     tile=64):
+                     tile=64, tail_ws=None):
         ntiles = tiles.shape[0]
         nrows, d = (S.shape if S is not None else (0, 0))
         ldw = Wh.stride(0) if Wh is not None else 0
         _lib.check(self.lib.vgan_mmd_gram_bf3(_ptr(Zh), _ptr(Zl), Zh.stride(0), _ptr(sq), int(n), _ptr(bw), _ptr(tiles), ntiles,
                                               int(tile), _ptr(Wh), _ptr(Wl), ldw, int(wrow0), _ptr(partial), _ptr(S),
                                               S.stride(0) if S is not None else 0, int(bool(from_softmax)), int(row_offset),
-                                              _ptr(colpart), nrows, d, self._stream()), "vgan_mmd_gram_bf3")
+                                              _ptr(colpart), nrows, d, _ptr(tail_ws), tail_ws.numel() * 4 if tail_ws is not None else 0,
+                                              self._stream()), "vgan_mmd_gram_bf3")
 
     def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
                          tile=0):

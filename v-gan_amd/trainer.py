@@ -306,6 +306,9 @@ class NoKLStepEngine:
             self.T = torch.zeros(n, e2, **f32)  # [z|1] . At_2^T
             self.T_ws = torch.zeros(((n + 63) // 64) * ((e2 + 63) // 64) * 64 * _round4(self.e[1]), **f32)
         self.perm = torch.zeros(self.nb, n, dtype=torch.int32, device=self.dev)
+        # the NEXT epoch's table, staged while the current epoch runs (stage_epoch_batches / begin_epoch)
+        self.perm_next = torch.zeros_like(self.perm)
+        self.epoch_staged = False
         # Gram tile edge: the split-bf16 Gram has a 128x128 variant (half the L2 -> LDS bytes per flop, one 512-thread
         # workgroup per CU).  Measured: c5 330 vs 273 TFLOP/s algorithmic, c3 (136 tiles of 128) no gain (26.3 vs 25.6 us),
         # so it is used once its table fills the chip twice over and the row shard is a whole number of tiles.
@@ -320,6 +323,10 @@ class NoKLStepEngine:
         if self.bf3 and nl % 256 == 0 and want in ("auto", "256"):
             if want == "256" or len(ops.build_tiles(n, 1, rank, world, device=self.dev, tile=256)) >= 512:
                 self.gram_tile = 256
+        # one 768-thread workgroup holds a CU, so a table runs in rounds of 256 tiles; the library splits a short last round over
+        # K when it is lent this workspace (include/vgan_hip.h, tail_ws: c4's 1 040 tiles = 4 rounds + 16 tiles)
+        self.gram_tail_ws = (ops.gram_tail_workspace(self.dev)
+                             if self.gram_tile == 256 and os.environ.get("VGAN_GRAM_TAIL", "1") != "0" else None)
         # Overlap of the step's tail with the only work of the NEXT step that needs no updated parameter: the X half of its
         # operand (gather, centre, split) and the X-X tiles of its Gram, which feed nothing but the reported loss.  They run on
         # a side stream that forks right after the MMD backward launch (whose riding step tail has advanced the batch cursor)
@@ -429,8 +436,28 @@ class NoKLStepEngine:
 
     # ---- host-side controls ---------------------------------------------------------------------
     def set_epoch_batches(self, idx):
-        """idx: [batches_per_epoch, n] integer tensor of shuffled row indices (DataLoader order)."""
-        self.perm.copy_(idx.to(dtype=torch.int32), non_blocking=True)
+        """idx: [batches_per_epoch, n] integer tensor of shuffled row indices (DataLoader order): the table of the epoch that
+        starts now (= stage_epoch_batches + begin_epoch)."""
+        if os.environ.get("VGAN_FEED_DIRECT") == "1":  # (A/B knob: the plain pageable copy of rounds 1-2)
+            self.perm.copy_(idx.to(dtype=torch.int32), non_blocking=True)
+            self._after_new_epoch_table()
+            return
+        self.stage_epoch_batches(idx)
+        self.begin_epoch()
+
+    def stage_epoch_batches(self, idx):
+        """Host half of an epoch boundary, callable right after the previous epoch's steps have been launched: the table goes
+        to a device staging buffer in stream order (behind those steps), so the host draw of the table (the DataLoader's
+        randperm: ~90 us for 16 384 rows) overlaps the GPU's work instead of preceding the epoch's first launch."""
+        self.perm_next.copy_(idx.to(dtype=torch.int32).view(self.nb, self.n), non_blocking=True)
+        self.epoch_staged = True
+
+    def begin_epoch(self):
+        """Device half: the staged table becomes the current one (a 4 n nb byte device copy, same stream)."""
+        if not self.epoch_staged:
+            raise RuntimeError("begin_epoch without a staged table (stage_epoch_batches)")
+        self.perm.copy_(self.perm_next)
+        self.epoch_staged = False
         self._after_new_epoch_table()
 
     def _after_new_epoch_table(self):
@@ -685,7 +712,7 @@ class NoKLStepEngine:
                 ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
         if bf3:
             ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles[:self.n_main], self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
-                             self.colpart, True, tile=self.gram_tile)
+                             self.colpart, True, tile=self.gram_tile, tail_ws=self.gram_tail_ws)
         else:
             ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles[:self.n_main], self.Wg, n + lo, self.partial, self.S, 0,
                                 self.colpart, True)
@@ -821,7 +848,7 @@ class NoKLStepEngine:
                 return
             if self.bf3:
                 ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles[t0:t1], self.Wh, self.Wl, n + lo, self.partial[t0:t1],
-                                 tile=self.gram_tile)
+                                 tile=self.gram_tile, tail_ws=self.gram_tail_ws)
             else:
                 ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles[t0:t1], False, self.Wg, n + lo, self.partial[t0:t1])
 

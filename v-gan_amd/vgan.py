@@ -321,7 +321,9 @@ class VGAN_no_kl(_RunFolder):
             if self.shuffle_source == "device":   # counter-based permutation evaluated on the GPU: no host draw, no copy
                 engine.shuffle_epoch(epoch)
             else:
-                engine.set_epoch_batches(epoch_batches(train_size, self.batch_size))
+                if not engine.epoch_staged:
+                    engine.stage_epoch_batches(epoch_batches(train_size, self.batch_size))
+                engine.begin_epoch()
             if self.noise_source == "host":
                 noise_tensor = torch.Tensor(self.batch_size, latent_size)  # src/vgan.py:594
             if self.noise_source == "host":
@@ -330,6 +332,11 @@ class VGAN_no_kl(_RunFolder):
                     engine.step()
             else:
                 engine.run_steps(batches_per_epoch)  # blocks of steps per graph launch (NoKLStepEngine.run_steps)
+                # the next epoch's table is drawn and uploaded while this epoch's steps run (only with device noise: host noise
+                # interleaves its draws with the DataLoader's on the same generator; and only if an epoch follows, so that the
+                # fit consumes exactly the reference's draws)
+                if self.shuffle_source != "device" and epoch + 1 < epochs:
+                    engine.stage_epoch_batches(epoch_batches(train_size, self.batch_size))
             generator_loss = engine.epoch_loss()  # the only host sync of the epoch
             if loss_function.kernel.bandwidth is None:
                 loss_function.kernel.bandwidth = engine.bw.view(())
