@@ -183,7 +183,7 @@ def kernel_rooflines(eng):
         nt = eng.tiles.shape[0] if eng.front_sharded else eng.n_main
         main_flop = 2.0 * D_FEAT * pairs_of(tl[:nt])
         ms = time_kernel(lambda: ops.mmd_gram_bf3(eng.Zh, eng.Zl, eng.sqn, n, eng.bw, eng.tiles[:nt], eng.Wh, eng.Wl, n + lo, eng.partial,
-                                                  tile=eng.gram_tile, tail_ws=eng.gram_tail_ws), iters)
+                                                  tile=eng.gram_tile, tail_ws=eng.gram_tail_ws, rs_part=eng.rs_part), iters)
         out[gname] = {"ms": ms, "tflops": main_flop / (ms * 1e-3) / 1e12, "flop": main_flop, "tiles": int(nt)}
         if nt < eng.tiles.shape[0]:
             xx_flop = 2.0 * D_FEAT * pairs_of(tl[nt:])
@@ -195,7 +195,7 @@ def kernel_rooflines(eng):
         bname = {256: "mmd_backward_bf3_wide_kernel", 128: "mmd_backward_bf3_big_kernel"}.get(bwd_edge, "mmd_backward_bf3_kernel<64>")  # the library's own choice
         if eng.rm_backward:  # B operand = the Gram's row-major images (transposed LDS reads)
             ms = time_kernel(lambda: ops.mmd_backward_bf3_rm(eng.Wh, eng.Wl, eng.Zh, eng.Zl, 2 * n, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl],
-                                                             eng.gU, eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile), iters)
+                                                             eng.gU, eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile, rs_part=eng.rs_part), iters)
         else:
             ms = time_kernel(lambda: ops.mmd_backward_bf3(eng.Wh, eng.Wl, eng.ZTh, eng.ZTl, eng.Z, n + lo, nl, d, eng.Z[lo:lo + nl], eng.gU,
                                                           eng.bsplits, gs, mul_shift=eng.center, tile=eng.bwd_tile), iters)

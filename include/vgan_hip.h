@@ -269,13 +269,17 @@ int vgan_mmd_bf3_prepare(const float* Z, int ldz, int rows, int p, uint16_t* Zh,
  * 768-thread workgroup holds a CU: ntiles mod CUs <= CUs / 2) has the tiles of that round computed by 2 or 4 workgroups
  * each, split over K; the partial products meet in the workspace and the last workgroup to arrive finishes the tile (sums in
  * part order: deterministic; nobody waits on anybody).  Results then differ from the unsplit launch by fp32 summation order
- * in those tiles only. */
+ * in those tiles only.
+ * rs_part (may be NULL; tile = 256, n a multiple of 128, W stored): float [ceil(2n / 128), ldrs], ldrs >= rows of W.  Every
+ * storing tile also leaves rs_part[c / 128][i - wrow0] = sum of the stored (hi + lo) weights of row i over the tile's columns
+ * c .. c + 127 -- the row sums vgan_mmd_backward_bf3_rm needs, taken from the epilogue's registers.  Cells of slots no tile
+ * covers are not written (zero them once). */
 int64_t vgan_mmd_gram_bf3_tail_ws_bytes(void);
 int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
                       const int32_t* tiles, int ntiles, int tile, uint16_t* Wh, uint16_t* Wl, int ldw,
                       int wrow0, float* partial, const float* S, int lds, int from_softmax, int row_offset,
                       uint64_t* colpart, int nrows, int d, void* tail_ws, int64_t tail_ws_bytes,
-                      vgan_stream_t stream);
+                      float* rs_part, int ldrs, vgan_stream_t stream);
 /* vgan_mmd_backward on the split operands: out = 2 (rowsum(W) z - W . Z) * mul with W = Wh + Wl [nr, kn]
  * and Z^T = ZTh + ZTl [kp, kn]; Z (fp32) is only read by the epilogue.  splits / slab_stride as in
  * vgan_mmd_backward (slabs of out, summed by the consumer in slab order); mul_shift as there.
@@ -291,12 +295,15 @@ int vgan_mmd_backward_bf3(const uint16_t* Wh, const uint16_t* Wl, int ldw, const
 /* The same backward product reading Z's ROW-MAJOR split images Zh, Zl [zrows, kp] -- the ones vgan_mmd_gram_bf3 reads -- so
  * that no transposed copy of Z has to be produced: the B fragments (8 consecutive contraction indices per lane) come out of a
  * row-major LDS image through ds_read_b64_tr_b16.  kn = the padded contraction length (columns of Wh / Wl, a multiple of 64,
- * >= zrows; columns >= zrows of W must be zero).  Everything else as vgan_mmd_backward_bf3. */
+ * >= zrows; columns >= zrows of W must be zero).  Everything else as vgan_mmd_backward_bf3.
+ * rs_part (may be NULL): the per-slot row sums a tile-256 vgan_mmd_gram_bf3 launch left beside W (rs_part [ceil(kn / 128), ldrs],
+ * ldrs >= nr).  The 256 x 128 kernel then folds them instead of having its loader waves sum the W rows from LDS (-5 % of the
+ * launch at c5); ignored by the other tile sizes and when a K split is not a whole number of 128-column slots. */
 int vgan_mmd_backward_bf3_rm(const uint16_t* Wh, const uint16_t* Wl, int ldw, int kn, const uint16_t* Zh,
                              const uint16_t* Zl, int kp, int zrows, const float* Z, int ldz, int wrow0, int nr,
                              int p, const float* mul, int ldmul, const float* mul_shift, float* out, int ldo,
                              int splits, int64_t slab_stride, int tile, const vgan_finalize_job* finalize,
-                             vgan_stream_t stream);
+                             const float* rs_part, int ldrs, vgan_stream_t stream);
 /* vgan_mmd_backward_bf3_rm on 64-wide tiles with a few X-X tiles of the Gram (struct vgan_xx_job; identity row map) riding in
  * the launch as surplus workgroups: the backward launch of the training step fills 416 of the chip's 512 workgroup slots for
  * 25 us, so up to ~90 eight-microsecond tiles cost it nothing.  The tiles' partial sums are complete when the launch is;

@@ -360,7 +360,8 @@ class CpuOps:
         return torch.zeros(4, dtype=torch.int32)  # (a scheduling aid of the HIP launch: nothing to mirror)
 
     def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True,
-                     tile=64, tail_ws=None):
+                     tile=64, tail_ws=None, rs_part=None):
+        assert rs_part is None or (tile == 256 and n % 128 == 0 and Wh is not None)
         zh, zl = self._bf(Zh), self._bf(Zl)
         s = _np(sq).astype(np.float64)
         bwv = float(bw.reshape(-1)[0])
@@ -385,12 +386,18 @@ class CpuOps:
                 if fl & TF_MIRROR:
                     Wh[np.ix_(cj - wrow0, ri)] = hi.t().contiguous().view(torch.int16)
                     Wl[np.ix_(cj - wrow0, ri)] = lo.t().contiguous().view(torch.int16)
+                if rs_part is not None:  # per 128-column slot: the sums of the stored hi + lo values
+                    v = hi.double().numpy() + lo.double().numpy()
+                    rs_part[c0 // 128, torch.as_tensor(ri - wrow0)] = torch.as_tensor(v.sum(1).astype(np.float32))
+                    if fl & TF_MIRROR:
+                        for h in range(0, len(ri), 128):
+                            rs_part[(r0 + h) // 128, torch.as_tensor(cj - wrow0)] = torch.as_tensor(v[h:h + 128].sum(0).astype(np.float32))
         partial.reshape(-1, 4)[:tiles.shape[0]].copy_(torch.as_tensor(part))
         if S is not None:
             self.colmax_partial(S, row_offset, colpart, from_softmax)
 
     def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
-                         tile=0):
+                         tile=0, rs_part=None):
         if finalize is not None:
             self.mmd_finalize(*finalize[0], **finalize[1])
         for q in range(1, splits):  # the whole product goes to slab 0
@@ -398,18 +405,21 @@ class CpuOps:
         wh, wl, th, tl = self._bf(Wh)[:nr], self._bf(Wl)[:nr], self._bf(ZTh)[:p], self._bf(ZTl)[:p]
         prod = wh @ th.T + wh @ tl.T + wl @ th.T
         z = _np(Z)[wrow0:wrow0 + nr, :p].astype(np.float64)
-        r = 2.0 * ((wh + wl).sum(1, keepdims=True) * z - prod)
+        rs = (wh + wl).sum(1, keepdims=True)
+        if rs_part is not None and self.mmd_backward_bf3_tile(nr, p, splits, tile) == 256:  # the Gram's per-slot sums, folded in slot order
+            rs = _np(rs_part)[:, :nr].astype(np.float32).astype(np.float64).sum(0)[:, None]
+        r = 2.0 * (rs * z - prod)
         if mul is not None:
             r = r * (_np(mul)[:nr, :p] + (_np(mul_shift)[:p] if mul_shift is not None else 0.0))
         out[:nr, :p].copy_(torch.as_tensor(r))
 
     def mmd_backward_bf3_rm(self, Wh, Wl, Zh, Zl, zrows, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
-                            tile=0, xx=None):
+                            tile=0, xx=None, rs_part=None):
         kn = (int(zrows) + 63) // 64 * 64
         ZTh = torch.zeros(Zh.shape[1], kn, dtype=torch.int16)
         ZTl = torch.zeros(Zh.shape[1], kn, dtype=torch.int16)
         ZTh[:, :zrows], ZTl[:, :zrows] = Zh[:zrows].t(), Zl[:zrows].t()
-        self.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits, slab_stride, finalize, mul_shift, tile)
+        self.mmd_backward_bf3(Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits, slab_stride, finalize, mul_shift, tile, rs_part)
         if xx is not None:  # X-X tiles riding in the launch: their sums are NOT seen by the tail of the same launch (it ran above)
             n = xx["Dh"].shape[0] // 2
             self.mmd_gram_bf3(xx["Dh"], xx["Dl"], xx["dsq"], n, xx["bw"], xx["tiles"], None, None, 0, xx["partial"])

@@ -63,7 +63,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.vgan_linear_forward(null, 0, 1, 0, null, 0, null, null, 0, 0, 0, 0, null) != 0
     assert b"bad argument" in lib.vgan_last_error()
     assert lib.vgan_mmd_gram(null, 0, null, 0, 0, null, null, 0, 0, null, 0, 0, null, null) != 0
-    assert lib.vgan_mmd_gram_bf3(null, null, 0, null, 0, null, null, 0, 64, null, null, 0, 0, null, null, 0, 0, 0, null, 0, 0, null, 0, null) != 0
+    assert lib.vgan_mmd_gram_bf3(null, null, 0, null, 0, null, null, 0, 64, null, null, 0, 0, null, null, 0, 0, 0, null, 0, 0, null, 0, null, 0, null) != 0
     assert lib.vgan_mask_project_forward_bf3(null, 0, null, 0, null, null, 1, 0, null, null, 0, null, null, null, 0, null, null, 0, 0, 0,
                                              null, 1, null, null, null) != 0
     assert lib.vgan_col_mean(null, 0, 0, 0, null, null) != 0

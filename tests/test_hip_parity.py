@@ -1385,6 +1385,56 @@ def test_backward_bf3_wide_tiles(ops, n, d, nr_of, splits):
     assert float((got - outs["t64"].sum(0).double()).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("n,d,mode,splits", [(1024, 520, 1, 1), (640, 300, 2, 1), (1024, 2048, 1, 2), (512, 256, 1, 3), (512, 256, 1, 6)])
+def test_row_sums_from_the_wide_gram(ops, n, d, mode, splits):
+    """The tile-256 Gram launch leaves the row sums of the stored W per 128-column slot (rs_part), and the 256 x 128 backward
+    kernel folds them instead of summing W's rows with its loader waves: every cell of rs_part equals the float64 sum of the
+    stored hi + lo weights over its slot (direct and mirrored stores, the tail-split tiles, ragged last slot), and the backward
+    product with rs_part equals the one without to fp32 rounding of the row sums -- two K slabs of whole slots use it, three
+    slabs of 384 = 3 x 128 columns use it, six slabs of 192 columns cut the slots and fall back to the loader sums."""
+    rng = np.random.default_rng(n + d)
+    N = 2 * n
+    dp = (d + 3) // 4 * 4
+    Z = torch.zeros(N, dp, device="cuda")
+    Z[:, :d] = dev((rng.normal(size=(N, d)) * (6.0 / np.sqrt(d))).astype(np.float32))
+    sq = torch.empty(N, device="cuda")
+    ops.row_sqnorm(Z, sq, d)
+    kp, kn = (d + 63) // 64 * 64, (N + 63) // 64 * 64
+    i16 = dict(dtype=torch.int16, device="cuda")
+    Zh, Zl = torch.zeros(N, kp, **i16), torch.zeros(N, kp, **i16)
+    ops.mmd_bf3_prepare(Z, N, d, Zh, Zl)
+    bw = torch.full((1,), 30.0, device="cuda")
+    nr, wrow0 = (n, n) if mode == 1 else (N, 0)
+    tiles = ops.build_tiles(n, mode, tile=256)
+    partial = torch.zeros(tiles.shape[0], 4, device="cuda")
+    Wh, Wl = torch.zeros(nr, kn, **i16), torch.zeros(nr, kn, **i16)
+    rs_part = torch.full(((N + 127) // 128, nr), float("nan"), device="cuda")
+    ops.mmd_gram_bf3(Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, tile=256, tail_ws=ops.gram_tail_workspace("cuda"), rs_part=rs_part)
+    w64 = (Wh.view(torch.bfloat16).double() + Wl.view(torch.bfloat16).double())[:, :N]
+    assert not bool(torch.isnan(rs_part).any()), "a slot of rs_part was left unwritten"
+    pad = torch.zeros(nr, rs_part.shape[0] * 128, dtype=torch.float64, device="cuda")
+    pad[:, :N] = w64
+    want_rs = pad.view(nr, -1, 128).sum(2).t()
+    assert float((rs_part.double() - want_rs).abs().max()) <= 4e-6 * float(want_rs.abs().max())
+    mul = dev(rng.normal(size=(nr, dp)).astype(np.float32))
+    outs = {}
+    for key, rsp in (("loaders", None), ("gram", rs_part), ("again", rs_part)):
+        o = torch.full((splits, nr, dp), float("nan"), device="cuda")
+        ops.mmd_backward_bf3_rm(Wh, Wl, Zh, Zl, N, Z, wrow0, nr, d, mul, o[0], splits, nr * dp, tile=256, rs_part=rsp)
+        outs[key] = o[:, :, :d].clone()
+    assert torch.equal(outs["gram"], outs["again"])
+    z64 = (Zh.view(torch.bfloat16).double() + Zl.view(torch.bfloat16).double())[:, :d]
+    want = 2.0 * (w64.sum(1, keepdim=True) * Z[wrow0:wrow0 + nr, :d].double() - w64 @ z64) * mul[:, :d].double()
+    scale = float((w64.abs().sum(1, keepdim=True) * Z[wrow0:wrow0 + nr, :d].abs().double()).max())
+    for key in ("loaders", "gram"):
+        assert float((outs[key].sum(0).double() - want).abs().max()) <= 1e-5 * scale, key
+    kchunk = ((kn // 64 + splits - 1) // splits) * 64
+    if splits == 1 or kchunk % 128 == 0:
+        assert not torch.equal(outs["gram"], outs["loaders"]), "rs_part was not used (same bits as the loader sums)"
+    else:
+        assert torch.equal(outs["gram"], outs["loaders"]), "a K split that cuts a slot must fall back to the loader sums"
+
+
 def test_two_sample_kernels_and_check_if_myopic(ops):
     """vgan_rbf_kernel_matrix / vgan_rows_dot against numpy, and check_if_myopic end to end on the GPU against the oracle's
     restatement of torch-two-sample (parity unpinned against that absent dependency)."""

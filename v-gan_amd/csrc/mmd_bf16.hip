@@ -309,7 +309,7 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
                                                                    const float* __restrict__ bw_ptr, const TileDesc* __restrict__ tiles,
                                                                    int ntiles, unsigned short* __restrict__ Wh,
                                                                    unsigned short* __restrict__ Wl, int ldw, int wrow0,
-                                                                   float* __restrict__ partial, ColmaxJob cj, TailSplit ts) {
+                                                                   float* __restrict__ partial, ColmaxJob cj, TailSplit ts, float* __restrict__ rs_part, int ldrs) {
     using G = GemmBF3Wide;
     constexpr int LDT = 132, LDM = 260;  // epilogue images Wt[256][LDT] (direct) and WtT[128][LDM] (mirrored), one at a time
     static_assert(256 * LDT * 4 <= G::kLdsBytes && 128 * LDM * 4 <= G::kLdsBytes, "epilogue images reuse the stage buffers");
@@ -413,8 +413,10 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
     if (store) {  // uniform per workgroup
         lds_f* Wt = (lds_f*)(float*)lds;
         // 16 consecutive weights of one output row -> hi / lo bf16 images (two 16-byte stores each when the run is whole)
-        auto emit = [&](const float (&w)[16], long rowo, int c_first, int c_lim) {
+        // ... and returns the sum of the stored values (hi + lo as the backward product will read them) over the valid columns
+        auto emit = [&](const float (&w)[16], long rowo, int c_first, int c_lim) -> float {
             unsigned hp[8], lp[8];
+            float sums[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 unsigned short h0, l0, h1, l1;
@@ -422,6 +424,9 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
                 split_bf16(w[2 * e + 1], h1, l1);
                 hp[e] = (unsigned)h0 | ((unsigned)h1 << 16);
                 lp[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+                const float v0 = __uint_as_float((unsigned)h0 << 16) + __uint_as_float((unsigned)l0 << 16);
+                const float v1 = __uint_as_float((unsigned)h1 << 16) + __uint_as_float((unsigned)l1 << 16);
+                sums[e & 3] += (c_first + 2 * e < c_lim ? v0 : 0.f) + (c_first + 2 * e + 1 < c_lim ? v1 : 0.f);
             }
             if (c_first + 15 < c_lim) {
                 uint4* dh = reinterpret_cast<uint4*>(Wh + rowo + c_first);
@@ -438,6 +443,14 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
                         Wl[rowo + c_first + e] = (unsigned short)(lp[e >> 1] >> (16 * (e & 1)));
                     }
             }
+            return (sums[0] + sums[1]) + (sums[2] + sums[3]);
+        };
+        // row sums of the stored W over one 128-column slot: the eight consecutive lanes that hold a row's chunks of the slot
+        auto slot_sum = [&](float v) -> float {
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            return v;
         };
         float w[16];
         if (cons) {  // direct image Wt[row][col]: for a fixed (i, j, r) the 64 lanes hit 64 different banks (4 * LDT = 16 mod 64)
@@ -451,13 +464,18 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
         __syncthreads();
         for (int t = threadIdx.x; t < 256 * 8; t += G::NTH) {  // all twelve waves store: row r0 + line, columns c0 + 16 q ..
             const int line = t >> 3, q16 = 16 * (t & 7);
+            float cs = 0.f;
             if (td.r0 + line < td.rlim && td.c0 + q16 < td.clim) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const f32x4 v = *(const lds_f4*)(Wt + line * LDT + q16 + 4 * e);
                     w[4 * e] = v[0]; w[4 * e + 1] = v[1]; w[4 * e + 2] = v[2]; w[4 * e + 3] = v[3];
                 }
-                emit(w, (long)(td.r0 + line - wrow0) * ldw, td.c0 + q16, td.clim);
+                cs = emit(w, (long)(td.r0 + line - wrow0) * ldw, td.c0 + q16, td.clim);
+            }
+            if (rs_part != nullptr) {  // (uniform; the trip count is a whole number of waves)
+                cs = slot_sum(cs);
+                if ((t & 7) == 0 && td.r0 + line < td.rlim) rs_part[(long)(td.c0 >> 7) * ldrs + (td.r0 + line - wrow0)] = cs;
             }
         }
         if (mirror) {  // mirrored image WtT[col][row]: a lane's four r are four consecutive rows -> one 16-byte LDS store per block
@@ -472,13 +490,19 @@ __global__ __launch_bounds__(768, 3) void mmd_gram_bf3_wide_kernel(const unsigne
             __syncthreads();
             for (int t = threadIdx.x; t < 128 * 16; t += G::NTH) {  // row c0 + line of W, columns r0 + 16 q ..
                 const int line = t >> 4, q16 = 16 * (t & 15);
+                float cs = 0.f;
                 if (td.c0 + line < td.clim && td.r0 + q16 < td.rlim) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const f32x4 v = *(const lds_f4*)(Wt + line * LDM + q16 + 4 * e);
                         w[4 * e] = v[0]; w[4 * e + 1] = v[1]; w[4 * e + 2] = v[2]; w[4 * e + 3] = v[3];
                     }
-                    emit(w, (long)(td.c0 + line - wrow0) * ldw, td.r0 + q16, td.rlim);
+                    cs = emit(w, (long)(td.c0 + line - wrow0) * ldw, td.r0 + q16, td.rlim);
+                }
+                if (rs_part != nullptr) {  // the row's sixteen chunks span two slots
+                    cs = slot_sum(cs);
+                    if ((t & 7) == 0 && td.c0 + line < td.clim && td.r0 + q16 < td.rlim)
+                        rs_part[(long)((td.r0 + q16) >> 7) * ldrs + (td.c0 + line - wrow0)] = cs;
                 }
             }
         }
@@ -630,7 +654,8 @@ __global__ __launch_bounds__(768, 3) void mmd_backward_bf3_wide_kernel(const uns
                                                                        const float* __restrict__ Z, int ldz, int wrow0, int nr, int p,
                                                                        int ptiles, const float* __restrict__ mul, int ldmul,
                                                                        const float* __restrict__ mul_shift, float* __restrict__ out, int ldo,
-                                                                       int kchunk, long slab_stride, int nb_cols, vgan_finalize_job job) {
+                                                                       int kchunk, long slab_stride, int nb_cols, vgan_finalize_job job,
+                                                                       const float* __restrict__ rs_part, int ldrs) {
     using G = GemmBF3Wide;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     __shared__ float rs[256];
@@ -653,7 +678,25 @@ __global__ __launch_bounds__(768, 3) void mmd_backward_bf3_wide_kernel(const uns
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4w{0.f, 0.f, 0.f, 0.f};
-    if (klen > 0)
+    if (klen > 0 && rs_part != nullptr) {
+        // row sums of W over this K range from the Gram launch's per-slot sums (128 columns each: vgan_mmd_gram_bf3, rs_part):
+        // 256 consumer threads fold one row each while the loaders bring in the first stages
+        if (threadIdx.x < 256) {
+            const float* src = rs_part + min(m0 + (int)threadIdx.x, nr - 1);
+            const int s0 = k0 >> 7, s1 = (k0 + klen + 127) >> 7;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int sl = s0;
+            for (; sl + 4 <= s1; sl += 4) {
+                a0 += src[(long)sl * ldrs];
+                a1 += src[(long)(sl + 1) * ldrs];
+                a2 += src[(long)(sl + 2) * ldrs];
+                a3 += src[(long)(sl + 3) * ldrs];
+            }
+            for (; sl < s1; ++sl) a0 += src[(long)sl * ldrs];
+            rs[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        }
+        G::run_bt<false>(Wh + k0, Wl + k0, ldw, Bh + (long)k0 * ldb, Bl + (long)k0 * ldb, ldb, nb_cols, brows - k0, m0, n0, nr, klen, lds, acc);
+    } else if (klen > 0)
         G::run_bt<true>(Wh + k0, Wl + k0, ldw, Bh + (long)k0 * ldb, Bl + (long)k0 * ldb, ldb, nb_cols, brows - k0, m0, n0, nr, klen, lds, acc, rs);
     if (G::is_loader()) return;  // (no barrier below)
 #pragma unroll
@@ -706,7 +749,8 @@ extern "C" int64_t vgan_mmd_gram_bf3_tail_ws_bytes(void) { return kTailSlabs * k
 extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp, const float* sq, int n, const float* bw,
                                  const int32_t* tiles, int ntiles, int tile, uint16_t* Wh, uint16_t* Wl, int ldw, int wrow0,
                                  float* partial, const float* S, int lds, int from_softmax, int row_offset, uint64_t* colpart,
-                                 int nrows, int d, void* tail_ws, int64_t tail_ws_bytes, vgan_stream_t stream) {
+                                 int nrows, int d, void* tail_ws, int64_t tail_ws_bytes, float* rs_part, int ldrs,
+                                 vgan_stream_t stream) {
     VGAN_CHECK_ARG(Zh && Zl && sq && bw && tiles && partial && n > 0 && ntiles > 0 && kp > 0 && kp % 64 == 0);
     VGAN_CHECK_ARG((Wh == nullptr) == (Wl == nullptr) && (reinterpret_cast<uintptr_t>(partial) & 15) == 0);
     VGAN_CHECK_ARG(aligned16(Zh) && aligned16(Zl) && (Wh == nullptr || (aligned16(Wh) && aligned16(Wl))));
@@ -718,6 +762,7 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
         extra = cj.nbx * ((nrows + kColChunkRows - 1) / kColChunkRows);
     }
     VGAN_CHECK_ARG(tile == 64 || tile == 128 || tile == 256);
+    VGAN_CHECK_ARG(rs_part == nullptr || (tile == 256 && Wh != nullptr && ldrs > 0 && wrow0 >= 0 && n % 128 == 0));
     if (tile == 256) {  // 256 x 128 tiles: 768-thread workgroups holding all but 16 KB of a CU's LDS
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_gram_bf3_wide_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, GemmBF3Wide::kLdsBytes);
@@ -744,7 +789,7 @@ extern "C" int vgan_mmd_gram_bf3(const uint16_t* Zh, const uint16_t* Zl, int kp,
         }
         const int nblk = ts.first + (ntiles - ts.first) * ts.parts;
         hipLaunchKernelGGL(mmd_gram_bf3_wide_kernel, dim3(nblk + extra), dim3(GemmBF3Wide::NTH), GemmBF3Wide::kLdsBytes, (hipStream_t)stream, Zh,
-                           Zl, kp, sq, n, bw, reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj, ts);
+                           Zl, kp, sq, n, bw, reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj, ts, rs_part, ldrs);
     } else if (tile == 128)
         hipLaunchKernelGGL(mmd_gram_bf3_big_kernel, dim3(ntiles + extra), dim3(512), 0, (hipStream_t)stream, Zh, Zl, kp, sq, n, bw,
                            reinterpret_cast<const TileDesc*>(tiles), ntiles, Wh, Wl, ldw, wrow0, partial, cj);
@@ -770,7 +815,8 @@ extern "C" int vgan_mmd_backward_bf3_tile(int nr, int p, int splits, int tile) {
 static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, int ldw, const uint16_t* Bh, const uint16_t* Bl, int kn, int kp,
                                int zrows, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
                                const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
-                               const vgan_finalize_job* finalize, vgan_stream_t stream, const vgan_xx_job* xxjob = nullptr) {
+                               const vgan_finalize_job* finalize, vgan_stream_t stream, const vgan_xx_job* xxjob = nullptr,
+                               const float* rs_part = nullptr, int ldrs = 0) {
     VGAN_CHECK_ARG(Wh && Wl && Bh && Bl && Z && out && nr > 0 && p > 0 && kn > 0 && kn % 64 == 0 && kp >= p && kp % 64 == 0);
     VGAN_CHECK_ARG(ldw >= kn && ldz >= p && ldo >= p && (mul == nullptr || ldmul >= p) && wrow0 >= 0);
     VGAN_CHECK_ARG(aligned16(Wh) && aligned16(Wl) && aligned16(Bh) && aligned16(Bl) && ldw % 8 == 0);
@@ -800,8 +846,10 @@ static int launch_backward_bf3(int rm, const uint16_t* Wh, const uint16_t* Wl, i
         VGAN_CHECK_ARG(attr == hipSuccess);
         const int pt = (p + 127) / 128;
         dim3 grid(pt * ((nr + 255) / 256) + nfin, splits);
+        // the Gram's per-slot row sums serve when every K range is a whole number of 128-column slots
+        if (rs_part != nullptr && !(ldrs >= nr && (splits == 1 || kchunk % 128 == 0))) rs_part = nullptr;
         hipLaunchKernelGGL(mmd_backward_bf3_wide_kernel, grid, dim3(GemmBF3Wide::NTH), GemmBF3Wide::kLdsBytes, st, Wh, Wl, ldw, Bh, Bl, kn, ldb,
-                           zrows, Z, ldz, wrow0, nr, p, pt, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, kp, job);
+                           zrows, Z, ldz, wrow0, nr, p, pt, mul, ldmul, mul_shift, out, ldo, kchunk, (long)slab_stride, kp, job, rs_part, ldrs);
         VGAN_CHECK_LAUNCH();
         return VGAN_OK;
     }
@@ -849,7 +897,7 @@ extern "C" int vgan_mmd_backward_bf3_rm_xx(const uint16_t* Wh, const uint16_t* W
 extern "C" int vgan_mmd_backward_bf3_rm(const uint16_t* Wh, const uint16_t* Wl, int ldw, int kn, const uint16_t* Zh, const uint16_t* Zl,
                                         int kp, int zrows, const float* Z, int ldz, int wrow0, int nr, int p, const float* mul, int ldmul,
                                         const float* mul_shift, float* out, int ldo, int splits, int64_t slab_stride, int tile,
-                                        const vgan_finalize_job* finalize, vgan_stream_t stream) {
+                                        const vgan_finalize_job* finalize, const float* rs_part, int ldrs, vgan_stream_t stream) {
     return launch_backward_bf3(1, Wh, Wl, ldw, Zh, Zl, kn, kp, zrows, Z, ldz, wrow0, nr, p, mul, ldmul, mul_shift, out, ldo, splits,
-                               slab_stride, tile, finalize, stream);
+                               slab_stride, tile, finalize, stream, nullptr, rs_part, ldrs);
 }

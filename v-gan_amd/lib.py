@@ -86,11 +86,11 @@ SIGNATURES = {
     "vgan_mmd_loss": (_i, [_p, _p, _i, _i, _f, _p, _p, _f, _p, _p]),
     "vgan_mmd_backward": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _p, _p]),
     "vgan_mmd_bf3_prepare": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
-    "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i64, _p]),
+    "vgan_mmd_gram_bf3": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i64, _p, _i, _p]),
     "vgan_mmd_gram_bf3_tail_ws_bytes": (_i64, []),
     "vgan_mmd_backward_bf3": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p]),
     "vgan_mmd_backward_bf3_tile": (_i, [_i, _i, _i, _i]),
-    "vgan_mmd_backward_bf3_rm": (_i, [_p, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p]),
+    "vgan_mmd_backward_bf3_rm": (_i, [_p, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _i, _p, _p, _i, _p]),
     "vgan_mmd_backward_bf3_rm_xx": (_i, [_p, _p, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _i, _i64, _p, _p, _p]),
     "vgan_row_sqnorm": (_i, [_p, _i, _p, _i, _i, _p]),
     "vgan_adadelta_step": (_i, [_p, _p, _i, _i64, _p, _p, _i64, _f, _f, _f, _f, _f, _p]),

@@ -333,7 +333,7 @@ class HipOps:
         return torch.zeros(int(self.lib.vgan_mmd_gram_bf3_tail_ws_bytes()) // 4, dtype=torch.int32, device=device)
 
     def mmd_gram_bf3(self, Zh, Zl, sq, n, bw, tiles, Wh, Wl, wrow0, partial, S=None, row_offset=0, colpart=None, from_softmax=True,
-                     tile=64, tail_ws=None):
+                     tile=64, tail_ws=None, rs_part=None):
         ntiles = tiles.shape[0]
         nrows, d = (S.shape if S is not None else (0, 0))
         ldw = Wh.stride(0) if Wh is not None else 0
@@ -341,7 +341,8 @@ class HipOps:
                                               int(tile), _ptr(Wh), _ptr(Wl), ldw, int(wrow0), _ptr(partial), _ptr(S),
                                               S.stride(0) if S is not None else 0, int(bool(from_softmax)), int(row_offset),
                                               _ptr(colpart), nrows, d, _ptr(tail_ws), tail_ws.numel() * 4 if tail_ws is not None else 0,
-                                              self._stream()), "vgan_mmd_gram_bf3")
+                                              _ptr(rs_part), rs_part.stride(0) if rs_part is not None else 0, self._stream()),
+                   "vgan_mmd_gram_bf3")
 
     def mmd_backward_bf3(self, Wh, Wl, ZTh, ZTl, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
                          tile=0):
@@ -355,9 +356,10 @@ class HipOps:
                    "vgan_mmd_backward_bf3")
 
     def mmd_backward_bf3_rm(self, Wh, Wl, Zh, Zl, zrows, Z, wrow0, nr, p, mul, out, splits=1, slab_stride=0, finalize=None, mul_shift=None,
-                            tile=0, xx=None):
+                            tile=0, xx=None, rs_part=None):
         """mmd_backward_bf3 on the ROW-MAJOR split images Zh, Zl [>= zrows, kp] (no transposed copies of Z).  xx: an xx_job() whose
-        X-X Gram tiles ride in the launch as surplus workgroups (64-wide tiles only)."""
+        X-X Gram tiles ride in the launch as surplus workgroups (64-wide tiles only).  rs_part: the per-slot row sums of W a
+        tile-256 mmd_gram_bf3 launch left (include/vgan_hip.h)."""
         _mat(Z, "Z"), _mat(out, "out")
         ldmul = mul.stride(0) if mul is not None else 0
         kn = (int(zrows) + 63) // 64 * 64
@@ -373,7 +375,8 @@ class HipOps:
         _lib.check(self.lib.vgan_mmd_backward_bf3_rm(_ptr(Wh), _ptr(Wl), Wh.stride(0), kn, _ptr(Zh), _ptr(Zl), Zh.stride(0), int(zrows),
                                                      _ptr(Z), Z.stride(0), int(wrow0), int(nr), int(p), _ptr(mul), ldmul, _ptr(mul_shift),
                                                      _ptr(out), out.stride(0), int(splits), int(slab_stride), int(tile),
-                                                     ctypes.byref(finalize) if finalize is not None else None, self._stream()),
+                                                     ctypes.byref(finalize) if finalize is not None else None, _ptr(rs_part),
+                                                     rs_part.stride(0) if rs_part is not None else 0, self._stream()),
                    "vgan_mmd_backward_bf3_rm")
 
     def mmd_backward_bf3_tile(self, nr, p, splits=1, tile=0):

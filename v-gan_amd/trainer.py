@@ -327,6 +327,12 @@ class NoKLStepEngine:
         # K when it is lent this workspace (include/vgan_hip.h, tail_ws: c4's 1 040 tiles = 4 rounds + 16 tiles)
         self.gram_tail_ws = (ops.gram_tail_workspace(self.dev)
                              if self.gram_tile == 256 and os.environ.get("VGAN_GRAM_TAIL", "1") != "0" else None)
+        # ... and its epilogue leaves the row sums of W per 128-column slot, which the 256 x 128 backward kernel folds instead of
+        # summing W's rows from LDS with its loader waves (-5 % of that launch at c5)
+        self.rs_part = None
+        if (self.gram_tile == 256 and self.rm_backward and n % 128 == 0 and os.environ.get("VGAN_RS_FROM_GRAM", "1") != "0"
+                and ops.mmd_backward_bf3_tile(nl, d, self.bsplits, self.bwd_tile) == 256):
+            self.rs_part = torch.zeros((2 * n + 127) // 128, nl, **f32)
         # Overlap of the step's tail with the only work of the NEXT step that needs no updated parameter: the X half of its
         # operand (gather, centre, split) and the X-X tiles of its Gram, which feed nothing but the reported loss.  They run on
         # a side stream that forks right after the MMD backward launch (whose riding step tail has advanced the batch cursor)
@@ -712,7 +718,7 @@ class NoKLStepEngine:
                 ops.mmd_bf3_prepare(self.Z, 2 * n, d, self.Zh, self.Zl, self.ZTh, self.ZTl)
         if bf3:
             ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles[:self.n_main], self.Wh, self.Wl, n + lo, self.partial, self.S, 0,
-                             self.colpart, True, tile=self.gram_tile, tail_ws=self.gram_tail_ws)
+                             self.colpart, True, tile=self.gram_tile, tail_ws=self.gram_tail_ws, rs_part=self.rs_part)
         else:
             ops.mmd_gram_colmax(self.Z, self.sqn, n, self.dp, self.bw, self.tiles[:self.n_main], self.Wg, n + lo, self.partial, self.S, 0,
                                 self.colpart, True)
@@ -732,7 +738,7 @@ class NoKLStepEngine:
             if self.rm_backward:
                 ops.mmd_backward_bf3_rm(self.Wh, self.Wl, self.Zh, self.Zl, 2 * n, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU,
                                         self.bsplits, gstride, fin, mul_shift=self.center, tile=self.bwd_tile,
-                                        xx=self._late_xx_job() if self.xx_late_in_backward else None)
+                                        xx=self._late_xx_job() if self.xx_late_in_backward else None, rs_part=self.rs_part)
             else:
                 ops.mmd_backward_bf3(self.Wh, self.Wl, self.ZTh, self.ZTl, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU, self.bsplits,
                                      gstride, fin, mul_shift=self.center, tile=self.bwd_tile)
@@ -848,7 +854,7 @@ class NoKLStepEngine:
                 return
             if self.bf3:
                 ops.mmd_gram_bf3(self.Zh, self.Zl, self.sqn, n, self.bw, self.tiles[t0:t1], self.Wh, self.Wl, n + lo, self.partial[t0:t1],
-                                 tile=self.gram_tile, tail_ws=self.gram_tail_ws)
+                                 tile=self.gram_tile, tail_ws=self.gram_tail_ws, rs_part=self.rs_part)
             else:
                 ops.mmd_gram(self.Z, self.sqn, n, self.dp, self.bw, self.tiles[t0:t1], False, self.Wg, n + lo, self.partial[t0:t1])
 
@@ -864,7 +870,7 @@ class NoKLStepEngine:
         gstride = nl * self.dp
         if self.bf3:
             ops.mmd_backward_bf3_rm(self.Wh, self.Wl, self.Zh, self.Zl, 2 * n, self.Z, n + lo, nl, d, self.Z[lo:lo + nl], self.gU,
-                                    self.bsplits, gstride, self._fin, mul_shift=self.center, tile=self.bwd_tile)
+                                    self.bsplits, gstride, self._fin, mul_shift=self.center, tile=self.bwd_tile, rs_part=self.rs_part)
         else:
             ops.mmd_backward(self.Wg, self.Z, n + lo, nl, 2 * n, self.dp, self.Z[lo:lo + nl], self.gU, self.bsplits, gstride, self._fin,
                              mul_shift=self.center)
