@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--front", choices=["auto", "replicated", "sharded"], default=None,
                     help="data-parallel front of the step (trainer.py; default: the engine's size rule)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--optional-seconds", type=float, default=600.0,
+                    help="budget of everything behind the metric's own leg (fp32 mode, c4 / c5 legs, CPU baseline): past it the line "
+                         "is printed as it stands and the process ends")
     return ap.parse_args()
 
 
@@ -513,21 +516,69 @@ def main():
     del eng
     torch.cuda.empty_cache()
 
+    # The one line, as far as the metric's own leg goes.  Everything below is OPTIONAL evidence added to the same line: a leg that
+    # raises is recorded as {"error": ...}, and if the optional legs together overrun --optional-seconds (a collective that never
+    # returns on some rank, say) a watchdog prints the line as it stands and ends the process, so that the metric is never lost
+    # to its side measurements.
+    out = {
+        "metric": f"V-GAN train steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": main_rate["value"], "unit": "steps/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": main_rate["ms_per_step"],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": ("f32; MMD contractions of `value`: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (centred operand); "
+                  "the same step with the fp32 MFMA is timed in `fp32_mode`") if main_bf3 else "f32", "data": "synthetic",
+        "config": main_cfg, "repeat_steps_per_s": main_rate["repeat_steps_per_s"],
+        "timing": f"median of {main_rate['repeats']} blocks of {steps} steps, each bracketed by barrier + synchronize, max over ranks",
+        "roofline": main_roof,
+    }
+    import threading
+    lock, printed = threading.Lock(), [False]
+
+    def emit(note=None):
+        with lock:
+            if printed[0]:
+                return
+            printed[0] = True
+            if note:
+                out["optional_legs"] = note
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+
+    def overrun():
+        emit(f"stopped by the watchdog after {args.optional_seconds:.0f} s; legs finished until then are in the line")
+        sys.stderr.write(f"[bench] rank {rank}: optional legs overran {args.optional_seconds:.0f} s, exiting\n")
+        sys.stderr.flush()
+        os._exit(0)
+
+    watchdog = threading.Timer(args.optional_seconds + (0.0 if rank == 0 else 5.0), overrun)
+    watchdog.daemon = True
+    watchdog.start()
+
+    def optional(name, fn):
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001 -- an optional leg must not take the metric with it
+            sys.stderr.write(f"[bench] optional leg {name} failed: {type(e).__name__}: {e}\n")
+            return {"error": f"{type(e).__name__}: {e}"}
+
     # The reference's own arithmetic is fp32 end to end.  When the engine's choice is the split-bf16 mode, the SAME
     # workload is timed a second time with the fp32-MFMA kernels (same warm-up discipline, same step count), so that the
     # driver's line carries a step rate for both arithmetic modes.
-    fp32_block = None
-    if main_bf3:
+    def fp32_leg():
         e32, _, _, b32, ml32 = timed_leg(steps, warmup, **{**ekw, "mmd_precision": "fp32"})
         r32 = rates(b32, steps)
-        fp32_block = {**r32, "unit": "steps/s", "warmup": warmup, "mmd_precision": "fp32", "mean_loss": ml32,
-                      "first_timed_step": e32.first_timed_step, "dtype": "f32 (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
-                      "roofline": roofline_of(e32, kernel_rooflines(e32), r32["value"], world)}
+        blk = {**r32, "unit": "steps/s", "warmup": warmup, "mmd_precision": "fp32", "mean_loss": ml32,
+               "first_timed_step": e32.first_timed_step, "dtype": "f32 (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
+               "roofline": roofline_of(e32, kernel_rooflines(e32), r32["value"], world)}
         del e32
         torch.cuda.empty_cache()
+        return blk
+
+    if main_bf3:
+        blk = optional("fp32_mode", fp32_leg)
+        with lock:
+            out["fp32_mode"] = blk
 
     # ---- the larger BASELINE.json configurations and the alternative exchange schedules, in the same invocation ----------
-    extra = {}
     if CONFIG == "c3" and not args.no_extra and not args.precision and not args.front:
         legs = []
         if world > 1:
@@ -541,44 +592,48 @@ def main():
         legs.append(("c5_bf16x3", "c5", {}))
         if world > 1:
             legs.append(("c5_bf16x3_replicated_front", "c5", dict(front="replicated")))
-        for name, cfg, kw in legs:
+
+        def extra_leg(cfg, kw):
             select_workload(cfg)
             k, w = (steps, warmup) if cfg == "c3" else (min(steps, 40 if cfg == "c4" else 16), min(warmup, 8))
             e, _, _, b, ml = timed_leg(k, w, **kw)
-            extra[name] = {"workload": WORKLOAD, **rates(b, k), "unit": "steps/s", "warmup": w, "n_gpus": world, "scaling": "strong",
-                           "global_batch": N_BATCH, "features": D_FEAT, "rows_per_gpu": e.nl, "mmd_precision": e.precision,
-                           "front": "sharded" if e.front_sharded else "replicated", "overlapped_allreduce": bool(e.overlap),
-                           "chain_association": "flops" if e.chain_flops else "depth", "gram_tile": e.gram_tile,
-                           "hip_graph": bool(graph_ok[0] and e.use_graph), "mean_loss": ml}
+            r = {"workload": WORKLOAD, **rates(b, k), "unit": "steps/s", "warmup": w, "n_gpus": world, "scaling": "strong",
+                 "global_batch": N_BATCH, "features": D_FEAT, "rows_per_gpu": e.nl, "mmd_precision": e.precision,
+                 "front": "sharded" if e.front_sharded else "replicated", "overlapped_allreduce": bool(e.overlap),
+                 "chain_association": "flops" if e.chain_flops else "depth", "gram_tile": e.gram_tile,
+                 "hip_graph": bool(graph_ok[0] and e.use_graph), "mean_loss": ml}
             del e
             torch.cuda.empty_cache()
+            return r
+
+        with lock:
+            out["extra"] = {}
+        for name, cfg, kw in legs:
+            r = optional(name, lambda: extra_leg(cfg, kw))
+            with lock:
+                out["extra"][name] = r
         select_workload(args.workload)
 
-    if rank == 0:
-        out = {
-            "metric": f"V-GAN train steps/sec (batch={N_BATCH}, d={D_FEAT})", "value": main_rate["value"], "unit": "steps/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": main_rate["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f32; MMD contractions of `value`: split-bf16 x3 on the bf16 MFMA with fp32 accumulation (centred operand); "
-                      "the same step with the fp32 MFMA is timed in `fp32_mode`") if main_bf3 else "f32", "data": "synthetic",
-            "config": main_cfg, "repeat_steps_per_s": main_rate["repeat_steps_per_s"],
-            "timing": f"median of {main_rate['repeats']} blocks of {steps} steps, each bracketed by barrier + synchronize, max over ranks",
-        }
-        out["roofline"] = main_roof
-        if fp32_block is not None:
-            out["fp32_mode"] = fp32_block
-        if extra:
-            out["extra"] = extra
-        if not args.no_cpu_baseline:  # rank 0, whatever N: the other ranks wait at the closing barrier
+    if rank == 0 and not args.no_cpu_baseline:  # rank 0, whatever N: the other ranks wait at the closing barrier
+
+        def cpu_leg():
             cb, cpu_loss, (X, z) = cpu_baseline(data, params, args.cpu_seconds)
-            out["cpu_baseline"] = cb
             gl = gpu_first_loss(params, X, z, mmd_precision=main_precision)
-            out["parity"] = {"mmd_precision": main_precision, "loss_gpu": gl, "loss_cpu_port": cpu_loss, "abs_diff": abs(gl - cpu_loss), "bar": 1e-4}
+            par = {"mmd_precision": main_precision, "loss_gpu": gl, "loss_cpu_port": cpu_loss, "abs_diff": abs(gl - cpu_loss), "bar": 1e-4}
             if main_bf3:
                 g32 = gpu_first_loss(params, X, z, mmd_precision="fp32")
-                out["parity"]["fp32_mode"] = {"loss_gpu": g32, "abs_diff": abs(g32 - cpu_loss)}
-            out["speedup_vs_cpu"] = main_rate["value"] / cb["value"]
-        print(json.dumps(out), flush=True)
+                par["fp32_mode"] = {"loss_gpu": g32, "abs_diff": abs(g32 - cpu_loss)}
+            return cb, par
+
+        res = optional("cpu_baseline", cpu_leg)
+        with lock:
+            if isinstance(res, dict):
+                out["cpu_baseline"] = res
+            else:
+                out["cpu_baseline"], out["parity"] = res
+                out["speedup_vs_cpu"] = main_rate["value"] / res[0]["value"]
+    watchdog.cancel()
+    emit()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -54,6 +54,40 @@ def _round4(v):
     return (v + 3) // 4 * 4
 
 
+def _launch_rounds(tiles, slots, can_split):
+    """Time of a Gram launch of `tiles` tiles in units of one full round of `slots` resident workgroups.  A partial last round
+    is NOT a whole round: with at most half the slots busy a tile runs about twice as fast (c5 wide tiles: 256 tiles 183 us,
+    272 tiles 276, 384 tiles 290; c4: 101, 153, 159), and the wide kernel's K split of a short last round (gram_tail_ws) brings
+    a remainder of up to an eighth / a quarter of the slots down to ~0.25 / ~0.4 of a round (c5: 16 tiles +28 us, 64 tiles +60)."""
+    if tiles <= 0:
+        return 0.0
+    full, r = divmod(tiles, slots)
+    if r == 0:
+        return float(full)
+    x = r / slots
+    last = 0.55 if x <= 0.5 else 0.55 + 0.9 * (x - 0.5)
+    if can_split and x <= 0.125:
+        last = 0.25
+    elif can_split and x <= 0.25:
+        last = 0.4
+    elif can_split and x <= 0.5:
+        last = 0.5
+    return full + last
+
+
+def _best_boundary(n_main, total, slots, can_split):
+    """First-part size <= n_main (tiles may only move to the SECOND launch, which runs after the all-gather and can take any tile)
+    that minimises the modelled time of the two launches; the boundary moves only for a gain of at least 0.15 round (the
+    model is not finer than that), and among equals as little as possible, so that most work stays beside the all-gather."""
+    cost = lambda k: _launch_rounds(k, slots, can_split) + _launch_rounds(total - k, slots, can_split)
+    best, best_cost = n_main, cost(n_main)
+    for k in range(n_main - 1, max(n_main - slots, 0), -1):
+        c = cost(k)
+        if c < best_cost - 1e-9 and c <= cost(n_main) - 0.15:
+            best, best_cost = k, c
+    return best
+
+
 class FlatParams:
     """Re-homes a module's parameters into one flat buffer (16-byte aligned offsets) so that Adadelta
     and the gradient all-reduce are single streaming passes.  ``module`` keeps working: each
@@ -392,10 +426,10 @@ class NoKLStepEngine:
             # two), so a first part of 3 x 256 + 4 tiles pays a fourth round for the four (c5, 8 ranks: 772 + 484 tiles, 352 + 198
             # us against ~100 us per round).  The boundary may move DOWN freely -- the second launch runs after the all-gather and
             # can take any tile -- so the tail of the first part goes over when the second part has free slots for it.
+            # `_best_boundary` puts it where the modelled time of the two launches is least (128-wide tiles, c5, 8 ranks:
+            # 772 + 484 -> 768 + 488).
             slots = 256 if self.gram_tile >= 128 else (512 if self.bf3 else 1024)  # (fp32 kernel: 36 KB of LDS, four workgroups per CU)
-            tail, second = self.n_main % slots, self.tiles.shape[0] - self.n_main
-            if 0 < tail < self.n_main and -(-(second + tail) // slots) == -(-second // slots):
-                self.n_main -= tail
+            self.n_main = _best_boundary(self.n_main, self.tiles.shape[0], slots, self.gram_tail_ws is not None)
         elif self.overlap or self.xx_ride or self.xx_in_m4:
             self.tiles, self.n_main = ops.build_tiles(n, 1, rank, world, device=self.dev, tile=self.gram_tile, split_xx=True)
             if self.xx_in_m4:
