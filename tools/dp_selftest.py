@@ -72,12 +72,21 @@ if world == 1:
                 if scheds[name] and front == "sharded":
                     continue  # (two schedules of the same exchange: the engine refuses the combination)
                 eng, data, params = bench.build_engine(0, G, True, force_exchange=True, overlap_exchange=scheds[name], front=front, **ekw)
-                bench.run_steps(eng, warm, 0)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                bench.run_steps(eng, steps, 0)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / steps
+                # warm until the clock has ramped (a first configuration timed right after its captures reads up to 40 % slow:
+                # c4 1/8 at 519-544 us instead of 373-381), then the median of three blocks
+                tw = time.perf_counter()
+                while True:
+                    bench.run_steps(eng, warm, 0)
+                    torch.cuda.synchronize()
+                    if time.perf_counter() - tw > 0.4:
+                        break
+                dts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    bench.run_steps(eng, steps, 0)
+                    torch.cuda.synchronize()
+                    dts.append((time.perf_counter() - t0) / steps)
+                dt = sorted(dts)[1]
                 print(f"{args.workload} {eng.precision} emulated shard 1/{G}, front {'sharded' if eng.front_sharded else 'replicated':10s} "
                       f"exchange schedule {name:7s}: {dt * 1e6:.1f} us per step per rank ({1.0 / dt:.0f} steps/s if collectives were free)",
                       flush=True)
