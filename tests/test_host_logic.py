@@ -366,3 +366,71 @@ def test_run_steps_needs_the_device_noise_stream():
     assert eng.steps_done == 1
     with pytest.raises(ValueError):
         eng.run_steps(2)
+
+
+def test_epoch_table_staged_behind_the_running_epoch():
+    """stage_epoch_batches + begin_epoch = set_epoch_batches; a table staged while an epoch runs does not disturb that epoch's
+    steps, and begin_epoch without a staged table is an error (the fit and bench.py stage the next epoch's table right after
+    launching the current epoch's steps)."""
+    g = load_golden("f2_step_c1.npz")
+    n = g["batch"].shape[0]
+    data = np.concatenate([g["batch"], g["batch"][::-1]])  # two batches per epoch
+    perm_a = torch.arange(2 * n).view(2, n)
+    perm_b = torch.arange(2 * n).flip(0).view(2, n)
+    losses = []
+    for staged in (False, True):
+        eng, _ = make_engine([g[f"param0_{i}"] for i in range(8)], data, n, 2)
+        out = []
+        if staged:
+            eng.stage_epoch_batches(perm_a)
+            eng.begin_epoch()
+            assert not eng.epoch_staged
+        else:
+            eng.set_epoch_batches(perm_a)
+        for step in range(4):
+            if step == 1 and staged:
+                eng.stage_epoch_batches(perm_b)  # mid-epoch: the running epoch keeps reading its own table
+                assert eng.epoch_staged and torch.equal(eng.perm, perm_a.to(torch.int32))
+            if step == 2:
+                if staged:
+                    eng.begin_epoch()
+                else:
+                    eng.set_epoch_batches(perm_b)
+                assert torch.equal(eng.perm, perm_b.to(torch.int32))
+            eng.set_noise(torch.as_tensor(g["noise"]))
+            eng.step()
+            out.append(float(eng.loss))
+        losses.append(out)
+        if staged:
+            with pytest.raises(RuntimeError):
+                eng.begin_epoch()
+    assert losses[0] == losses[1]
+
+
+def test_gram_launch_round_model_and_boundary():
+    """_launch_rounds / _best_boundary (the boundary between the two Gram launches of the sharded front): the modelled time grows
+    with the tile count inside a round, a K-split remainder is never dearer than a whole one, the boundary only moves down, never
+    to zero, never to a dearer place, and stays put unless the model gains at least 0.15 round."""
+    from vgan_amd.trainer import _best_boundary, _launch_rounds
+    for slots in (256, 512, 1024):
+        for can_split in (False, True):
+            prev = 0.0
+            for t in range(1, 3 * slots + 1):
+                c = _launch_rounds(t, slots, can_split)
+                if t % slots != 1 and not can_split:
+                    assert c >= prev - 1e-12
+                assert c <= _launch_rounds(t, slots, False) + 1e-12
+                assert (t + slots - 1) // slots - 0.75 - 1e-9 <= c <= (t + slots - 1) // slots
+                prev = c
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        slots = int(rng.choice([256, 512, 1024]))
+        total = int(rng.integers(2, 6 * slots))
+        n_main = int(rng.integers(1, total))
+        can_split = bool(rng.integers(0, 2))
+        cost = lambda k: _launch_rounds(k, slots, can_split) + _launch_rounds(total - k, slots, can_split)
+        k = _best_boundary(n_main, total, slots, can_split)
+        assert 1 <= k <= n_main
+        assert k == n_main or cost(k) <= cost(n_main) - 0.15 + 1e-9
+    assert _best_boundary(772, 1256, 256, False) == 768   # c5, 8 ranks, 128-wide tiles: the four stragglers go over
+    assert _best_boundary(388, 632, 256, True) == 388     # c5, 8 ranks, wide tiles: nothing to gain
