@@ -462,6 +462,8 @@ class NoKLStepEngine:
         self.has_bw = False
         self.loss = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
+        self._hist, self._hist_n, self._hist_events = None, 0, []  # per-epoch mean losses kept on the device (close_epoch)
+        self._read_stream, self._loss_host = None, None
         self.accum_scale = (1.0 / self.nb) if loss_accum_scale is None else float(loss_accum_scale)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         # column arg-max keys of topk(U, 1, 0): per 64-row chunk, folded by max in the step tail.  Sharded front: one slice of
@@ -566,6 +568,44 @@ class NoKLStepEngine:
         v = float(self._sum_over_ranks(self.loss_accum).item())
         self.loss_accum.zero_()
         return v
+
+    def close_epoch(self):
+        """Device half of an epoch's loss read-out: the accumulated mean loss moves into the next slot of a device-side history
+        (summed over the ranks when there are several) and the accumulator is cleared -- stream-ordered, no host sync.  Returns the
+        slot; `read_epoch_loss(slot)` fetches it later, on a side stream, without waiting for work launched in between, so that
+        a fit can report epoch e while the GPU already runs epoch e + 1."""
+        if self._hist is None or self._hist_n == self._hist.numel():
+            grown = torch.zeros(max(64, 2 * self._hist_n), dtype=torch.float32, device=self.dev)
+            if self._hist is not None:
+                grown[:self._hist_n].copy_(self._hist)
+            self._hist = grown
+        slot = self._hist_n
+        cell = self._hist[slot:slot + 1]
+        cell.copy_(self.loss_accum)
+        self.loss_accum.zero_()
+        if self.exchange:
+            self._collect().all_reduce(cell, group=self.group)
+        ev = None
+        if self.data.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._hist_events.append(ev)
+        self._hist_n += 1
+        return slot
+
+    def read_epoch_loss(self, slot):
+        """Host half: the mean loss `close_epoch` stored in `slot` (waits for that epoch only)."""
+        ev = self._hist_events[slot]
+        if ev is None:
+            return float(self._hist[slot])
+        if self._read_stream is None:
+            self._read_stream = torch.cuda.Stream(self.dev)
+            self._loss_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._read_stream.wait_event(ev)
+        with torch.cuda.stream(self._read_stream):
+            self._loss_host.copy_(self._hist[slot:slot + 1], non_blocking=True)
+        self._read_stream.synchronize()
+        return float(self._loss_host[0])
 
     def step_loss(self):
         """Loss of the last step (one host sync; with several ranks also one tiny all-reduce: `loss` holds this rank's share)."""

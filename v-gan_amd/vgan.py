@@ -315,8 +315,19 @@ class VGAN_no_kl(_RunFolder):
         engine = self._make_engine(generator, data, batches_per_epoch, loss_function)
         self._engine = engine
 
-        for epoch in range(epochs):
+        # An epoch's loss is reported AFTER the next epoch's steps have been launched (the read-out waits for its own epoch only:
+        # NoKLStepEngine.close_epoch / read_epoch_loss), so the GPU never idles behind the host's print, history append and next
+        # launches; the printed lines keep the reference's order (src/vgan.py:589-625).
+        pending = None
+
+        def report(slot):
+            generator_loss = engine.read_epoch_loss(slot)
             if self.verbose:
+                print(f"Average loss in the epoch: {generator_loss}")
+            self.train_history["generator_loss"].append(generator_loss)
+
+        for epoch in range(epochs):
+            if self.verbose and epoch == 0:
                 print(f"\rEpoch {epoch} of {epochs}")
             if self.shuffle_source == "device":   # counter-based permutation evaluated on the GPU: no host draw, no copy
                 engine.shuffle_epoch(epoch)
@@ -337,13 +348,22 @@ class VGAN_no_kl(_RunFolder):
                 # fit consumes exactly the reference's draws)
                 if self.shuffle_source != "device" and epoch + 1 < epochs:
                     engine.stage_epoch_batches(epoch_batches(train_size, self.batch_size))
-            generator_loss = engine.epoch_loss()  # the only host sync of the epoch
+            slot = engine.close_epoch()
             if loss_function.kernel.bandwidth is None:
                 loss_function.kernel.bandwidth = engine.bw.view(())
             self.bandwidth = loss_function.kernel.bandwidth
-            if self.verbose:
-                print(f"Average loss in the epoch: {generator_loss}")
-            self.train_history["generator_loss"].append(generator_loss)
+            if os.environ.get("VGAN_FIT_SYNC_EACH_EPOCH") == "1":  # (A/B knob: report at once, as rounds 1-2 did)
+                report(slot)
+                if self.verbose and epoch + 1 < epochs:
+                    print(f"\rEpoch {epoch + 1} of {epochs}")
+                continue
+            if pending is not None:
+                report(pending)
+                if self.verbose:
+                    print(f"\rEpoch {epoch} of {epochs}")
+            pending = slot
+        if pending is not None:
+            report(pending)
 
         self.generator = generator
         if self.path_to_directory is not None:
