@@ -414,6 +414,135 @@ __global__ __launch_bounds__(768, 3) void k_pp(const unsigned short* Zh, const u
     }
 }
 
+// Variant: ONE consumer wave per SIMD holding a 128 x 64 quadrant (8 x 4 blocks of 16 x 16: 128 accumulator registers), 4 loader
+// waves, ONE barrier per stage.  A stage's 24 fragment reads (B first, then the A blocks in the order they are used) are all issued
+// at its head -- behind the last MFMAs of the stage before -- and the MFMAs of row block i start when ITS two reads have landed
+// (counted lgkmcnt); the barrier that hands the buffer back sits behind the last read, in front of the last 12 MFMAs.  Per stage
+// and CU: 96 KB of fragment reads instead of 128, no read phase that the matrix pipe waits out.
+struct WideQ {
+    static constexpr int BM = 256, BN = 128, BK = 32, NTH = 512, NST = 3;
+    static constexpr int PA = BM * BK * 2, PB = BN * BK * 2, STAGE = 2 * PA + 2 * PB, kLdsBytes = NST * STAGE;
+    typedef char __attribute__((address_space(3))) lds_c;
+    __device__ static __forceinline__ int hsw(int r) { return (-(r >> 2)) & 3; }
+    __device__ static __forceinline__ void bar() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int N>
+    __device__ static __forceinline__ void wait_lgkm() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ static __forceinline__ void run(const unsigned short* Ah, const unsigned short* Al, long lda, const unsigned short* Bh,
+                                               const unsigned short* Bl, long ldb, int m0, int n0, int M, int N, int K, char* lds_generic,
+                                               f32x4v (&acc)[8][4]) {
+        lds_c* lds = (lds_c*)lds_generic;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int nk = K / BK;  // (>= 3 assumed in this prototype)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (wave >= 4) {
+            __builtin_amdgcn_s_setprio(3);
+            const int lw = wave - 4;
+            const char* src[12];
+            int dst[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int pc = 12 * lw + e;
+                const int part = pc < 16 ? 0 : pc < 32 ? 1 : pc < 40 ? 2 : 3;
+                const int pin = part == 0 ? pc : part == 1 ? pc - 16 : part == 2 ? pc - 32 : pc - 40;
+                const int row = 16 * pin + (lane >> 2);
+                const int c = (lane & 3) ^ hsw(row);
+                const unsigned short* base = part == 0 ? Ah : part == 1 ? Al : part == 2 ? Bh : Bl;
+                const long ld = part < 2 ? lda : ldb;
+                const int g0 = part < 2 ? m0 : n0, lim = part < 2 ? M : N;
+                src[e] = reinterpret_cast<const char*>(base + (long)min(g0 + row, lim - 1) * ld) + 16 * c;
+                dst[e] = (part == 0 ? 0 : part == 1 ? PA : part == 2 ? 2 * PA : 2 * PA + PB) + pin * 1024;
+            }
+            auto fill = [&](int kt) {
+                lds_c* d = lds + (kt % NST) * STAGE;
+#pragma unroll
+                for (int e = 0; e < 12; ++e)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src[e] + 2 * (long)kt * BK),
+                                                     (void __attribute__((address_space(3)))*)(d + dst[e]), 16, 0, 0);
+            };
+            fill(0); fill(1); fill(2);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (24 & 15) | ((24 >> 4) << 14));  // vmcnt(24): stage 0 landed
+            bar();  // P
+            for (int kt = 0; kt < nk; ++kt) {  // B(kt): everyone has read stage kt; stage kt + 1 has landed
+                if (kt + 1 < nk) {
+                    if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | 12); else __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+                bar();
+                if (kt + 3 < nk) fill(kt + 3);
+            }
+            return;
+        }
+        const int R = wave >> 1, C = wave & 1;
+        const int fr = lane & 15, fc = lane >> 4;
+        const int posA = (fc ^ hsw(fr)) << 4;
+        u32x4 ah[8], al[8], bh[4], bl[4];
+        bar();  // P
+        for (int kt = 0; kt < nk; ++kt) {
+            const lds_c* st = lds + (kt % NST) * STAGE;
+            const lds_c* pa = st + (R * 128 + fr) * 64 + posA;
+            const lds_c* pb = st + 2 * PA + (C * 64 + fr) * 64 + posA;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bh[b] = *(const lds_u4*)(pb + b * 1024);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bl[b] = *(const lds_u4*)(pb + PB + b * 1024);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                al[b] = *(const lds_u4*)(pa + PA + b * 1024);
+                ah[b] = *(const lds_u4*)(pa + b * 1024);
+            }
+            auto group = [&](int i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+            };
+            wait_lgkm<14>(); group(0);
+            wait_lgkm<12>(); group(1);
+            wait_lgkm<10>(); group(2);
+            wait_lgkm<8>(); group(3);
+            wait_lgkm<6>(); group(4);
+            wait_lgkm<4>(); group(5);
+            wait_lgkm<2>(); group(6);
+            wait_lgkm<0>();
+            bar();       // B(kt): the buffer goes back to the loaders
+            group(7);
+        }
+    }
+};
+
+__global__ __launch_bounds__(512, 2) void k_q(const unsigned short* Zh, const unsigned short* Zl, int kp, int ld, int N, int tiles_per_row, float* out, float* tile0) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int per = gridDim.x / 8, t = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const int blk = t / 32, in = t % 32, bpr = tiles_per_row / 8;
+    const int r0 = ((blk / bpr) * 4 + in / 8) * 256, c0 = ((blk % bpr) * 8 + in % 8) * 128;
+    f32x4v acc[8][4];
+    WideQ::run(Zh, Zl, ld, Zh, Zl, ld, r0, c0, N, N, kp, lds, acc);
+    if (threadIdx.x >= 256) return;
+    float s = 0;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
+    if (r0 == 0 && c0 == 128 && tile0 != nullptr) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, R = wave >> 1, C = wave & 1;
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r)
+            tile0[(128 * R + 16 * i + 4 * (lane >> 4) + r) * 128 + 64 * C + 16 * j + (lane & 15)] = acc[i][j][r];
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void k_big(const unsigned short* Zh, const unsigned short* Zl, int kp, int ld, int N, int tiles_per_row, float* out) {
     using G = GemmBF3Big;
     __shared__ __attribute__((aligned(16))) char lds[G::kLdsBytes];
@@ -443,6 +572,7 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<Wide>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pp), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_q), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<false, true, true>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<true, false, true>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<WideT<false, true, false>>), hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLdsBytes);
@@ -473,10 +603,14 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_pp, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, tile0);
     hipMemcpy(t1.data(), tile0, t1.size() * 4, hipMemcpyDeviceToHost);
     printf("staggered-group variant equals the plain wide loop bit for bit: %s\n", memcmp(t0.data(), t1.data(), t0.size() * 4) == 0 ? "yes" : "NO");
+    hipMemset(tile0, 0, 256 * 128 * 4);
+    hipLaunchKernelGGL(k_q, dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, tile0);
+    hipMemcpy(t1.data(), tile0, t1.size() * 4, hipMemcpyDeviceToHost);
+    printf("one-consumer-wave-per-SIMD variant equals the plain wide loop bit for bit: %s\n", memcmp(t0.data(), t1.data(), t0.size() * 4) == 0 ? "yes" : "NO");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
-        const char* names[] = {"big 128x128x64 (2 st)", "wide 256x128x32 (3 st)", "wide, no fill", "wide, no MFMA", "wide, MFMA only", "wide, fill only", "wide + 4 loader waves", "loaders + staggered groups"};
-        for (int which = 0; which < 8; ++which) {
+        const char* names[] = {"big 128x128x64 (2 st)", "wide 256x128x32 (3 st)", "wide, no fill", "wide, no MFMA", "wide, MFMA only", "wide, fill only", "wide + 4 loader waves", "loaders + staggered groups", "4 x (128 x 64) consumers"};
+        for (int which = 0; which < 9; ++which) {
             auto launch = [&]() {
                 float* nul = nullptr;
                 if (which == 0) hipLaunchKernelGGL(k_big, dim3(ntB), dim3(512), 0, 0, Zh, Zl, kp, ld, N, tprB, out);
@@ -486,7 +620,8 @@ int main(int argc, char** argv) {
                 else if (which == 4) hipLaunchKernelGGL((k_wide<WideT<false, true, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
                 else if (which == 5) hipLaunchKernelGGL((k_wide<WideT<true, false, false>>), dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
                 else if (which == 6) hipLaunchKernelGGL(k_lw, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
-                else hipLaunchKernelGGL(k_pp, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else if (which == 7) hipLaunchKernelGGL(k_pp, dim3(ntW), dim3(768), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
+                else hipLaunchKernelGGL(k_q, dim3(ntW), dim3(512), Wide::kLdsBytes, 0, Zh, Zl, kp, ld, N, tprW, out, nul);
             };
             for (int i = 0; i < 10; ++i) launch();
             hipEventRecord(e0);
